@@ -1,0 +1,179 @@
+/*
+ * mgvae.h -- C ABI of libmgvae_hip.so: the MI355X (gfx950) kernels behind the bar-VAE
+ * training hot path of KMU-AELAB-MusicProject/MusicGeneration_VAE-torch.
+ *
+ * The reference has no FFI: its hot path is reached through torch.nn modules
+ * (graph/*.py) that dispatch to ATen/cuDNN.  Each entry point below replaces the
+ * library kernel(s) one reference module call issues; the citation on every
+ * prototype names that call site (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes; all tensors are fp32, NCHW, device memory owned by the
+ *     caller (PyTorch's allocator); nothing is allocated, freed or retained here;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*);
+ *     no implicit synchronisation, safe under hipGraph stream capture;
+ *   - return 0 on success, a negative MGVAE_E* code otherwise (mgvae_strerror());
+ *   - "accumulate" outputs (weight / bias / affine gradients, embedding gradient) are
+ *     ADDED into the destination, which the caller zeroes once per optimizer step;
+ *   - channel-sliced tensors: a tensor argument described by (ctot, coff) is the
+ *     channel range [coff, coff+C) of a buffer with ctot channels, so concatenations
+ *     (torch.cat(dim=1) in the reference) are written in place with no copy.
+ */
+#ifndef MGVAE_H
+#define MGVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGVAE_OK 0
+#define MGVAE_EINVAL (-1)   /* bad descriptor / null pointer / unsupported geometry */
+#define MGVAE_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+#define MGVAE_ENODEV (-3)   /* no gfx950 device / wrong architecture */
+
+enum { MGVAE_ACT_NONE = 0, MGVAE_ACT_RELU = 1, MGVAE_ACT_LEAKY = 2, MGVAE_ACT_SIGMOID = 3 };
+
+/* Geometry of one convolution, always in CONVOLUTION sense:
+ *   X [N, x_ctot, H,  W ]  channels [x_coff, x_coff+Cx)   (the larger, "image" side)
+ *   Y [N, y_ctot, OH, OW]  channels [y_coff, y_coff+Cy)   (the "feature" side)
+ *   Wt[Cy, Cx, KH, KW]     (torch Conv2d layout; a ConvTranspose2d weight
+ *                           [Cin_T, Cout_T, kh, kw] is the same memory with
+ *                           Cy = Cin_T, Cx = Cout_T)
+ *   OH = (H + 2*PH - KH) / SH + 1, likewise OW (output_padding of a transposed
+ *   convolution is absorbed in H/W).
+ * act/slope: activation fused on the tensor the call WRITES (fwd: Y, bwd_data /
+ * transposed fwd: X).                                                              */
+typedef struct MgvaeConvDesc {
+    int32_t N, Cx, H, W, Cy, OH, OW;
+    int32_t KH, KW, SH, SW, PH, PW;
+    int32_t x_ctot, x_coff, y_ctot, y_coff;
+    int32_t act;
+    float slope;
+} MgvaeConvDesc;
+
+const char* mgvae_strerror(int code);
+/* library / device probe: returns 0 and fills arch string ("gfx950...") + CU count */
+int mgvae_device_info(char* arch, size_t arch_len, int* cu_count);
+
+/* ---- convolution family (implicit GEMM on v_mfma_f32_32x32x2_f32) -----------------
+ * nn.Conv2d forward:  graph/encodingBlock.py:12-15,43-46,74-77,107-108;
+ * graph/decoder.py:79,122,172,175; nn.Linear (H=W=1): graph/encoder.py:22,38,
+ * graph/decoder.py:166-167, graph/z_discriminator.py:13-24                            */
+int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
+                     float* y, void* stream);
+/* dX of nn.Conv2d == forward of nn.ConvTranspose2d (graph/decoder.py:12-15,43-46,
+ * 73-77,116-120): X = conv_transpose(Y, Wt) (+ bias[Cx]), stride-phase decomposed    */
+int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
+                          float* x, void* stream);
+/* dWt += corr(X, Y): weight gradient of either layer type (split-K, fp32 atomics)    */
+int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
+                            void* stream);
+/* db[c] += sum_{n,h,w} t[n, coff+c, h, w]   (bias gradient of Conv/ConvT/Linear)     */
+int mgvae_channel_sum_accum(const float* t, int N, int C, int P, int ctot, int coff, float* db,
+                            void* stream);
+
+/* ---- InstanceNorm2d(affine, eps, no running stats) + fused activation -------------
+ * graph/encodingBlock.py:17,48,79,110; graph/decoder.py:17,48,81-83,124-126,173
+ * x [N,C,P] contiguous; y is channel-sliced; stats[N*C*2] = (mean, rstd) saved for bwd */
+int mgvae_instance_norm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                            float* stats, int N, int C, int P, int y_ctot, int y_coff,
+                            float eps, int act, float slope, void* stream);
+/* dy is channel-sliced like y; dx contiguous; dgamma/dbeta accumulate                 */
+int mgvae_instance_norm_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
+                            const float* dy, float* dx, float* dgamma, float* dbeta,
+                            int N, int C, int P, int dy_ctot, int dy_coff, int act, float slope,
+                            void* stream);
+
+/* ---- CBAM (graph/cbam.py:22-29,43-52,63-67) fused with the residual that follows it
+ * mode 0: y = cbam(u)                      (graph/cbam.py CBAM.forward)
+ * mode 1: y = act(u + cbam(u))             (graph/encodingBlock.py:32,63,122; decoder.py:32,62,103,140,150,213)
+ * mode 2: y = act(res + cbam(u))           (graph/encodingBlock.py:94-98)
+ * u [N,C,P] contiguous, P = H*W; w1 [C/16,C], w2 [C,C/16], wsp [1,2,3,3].
+ * Workspace `save` (floats, size mgvae_cbam_save_floats) keeps what backward needs.   */
+size_t mgvae_cbam_save_floats(int N, int C, int H, int W);
+int mgvae_cbam_fwd(const float* u, const float* res, const float* w1, const float* w2, const float* wsp,
+                   float* y, float* save, int N, int C, int H, int W, int y_ctot, int y_coff,
+                   int mode, int act, float slope, void* stream);
+/* du (contiguous) and dres (contiguous, mode 2 only) are written; dw1/dw2/dwsp accumulate.
+ * y/dy are channel-sliced (ctot, coff).  `scratch` needs mgvae_cbam_bwd_scratch_floats.  */
+size_t mgvae_cbam_bwd_scratch_floats(int N, int C, int H, int W);
+int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, const float* w1, const float* w2,
+                   const float* wsp, const float* save, float* du, float* dres, float* dw1, float* dw2,
+                   float* dwsp, float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff,
+                   int mode, int act, float slope, void* stream);
+
+/* ---- pointwise / small ops ---------------------------------------------------------*/
+/* dx = dy * act'(y) given the activation OUTPUT y (ReLU/LeakyReLU/Sigmoid); all three
+ * tensors may be channel slices of [N, ctot, P] buffers                               */
+int mgvae_act_bwd(const float* y, const float* dy, float* dx, int N, int C, int P,
+                  int y_ctot, int y_coff, int dy_ctot, int dy_coff, int dx_ctot, int dx_coff,
+                  int act, float slope, void* stream);
+/* strided row copy (torch.cat / slicing along channels): dst[r, 0:width] = src[r, 0:width] */
+int mgvae_copy2d(float* dst, size_t dpitch, const float* src, size_t spitch, size_t width, size_t rows,
+                 void* stream);
+/* dst[i] += src[i] */
+int mgvae_add_inplace(float* dst, const float* src, size_t n, void* stream);
+/* out[r] = mean(x[r, 0:L]) -- nn.AvgPool2d over the whole map, graph/encoder.py:20,35;
+ * graph/phrase_encoder.py:21,36; bwd: dx[r, l] = dout[r] / L                          */
+int mgvae_rowmean_fwd(const float* x, float* out, int rows, int L, void* stream);
+int mgvae_rowmean_bwd(const float* dout, float* dx, int rows, int L, void* stream);
+/* nn.Embedding gather (graph/decoder.py:187,193) into a row-sliced destination and its
+ * scatter-add gradient                                                                */
+int mgvae_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int D, int rows,
+                        size_t out_pitch, void* stream);
+int mgvae_embedding_bwd(const int64_t* idx, const float* dout, float* dtable, int B, int D, int rows,
+                        size_t dout_pitch, void* stream);
+/* nn.Dropout(p) (graph/decoder.py:164,196,201): Philox4x32-10 keyed by (seed, offset);
+ * mask (float {0, 1/(1-p)}) is written for backward / parity tests                    */
+int mgvae_dropout_fwd(const float* x, float* y, float* mask, size_t n, float p, uint64_t seed,
+                      uint64_t offset, void* stream);
+int mgvae_mul(const float* a, const float* b, float* out, size_t n, void* stream);
+/* Gaussian prior noise randn*sigma (agent/barGen2.py:243,250; barGen_with_gan.py:517) */
+int mgvae_randn(float* out, size_t n, float sigma, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- losses (graph/loss/bar_loss.py:23-33,41-42) -------------------------------------
+ * BCE(mean) with torch's log clamp at -100.  target_mode 0: targets[i]; 1: label
+ * smoothing targets[i]*0.82 + 0.1/60 + prior[i % 60]*0.08 (prior = 60 floats, already
+ * multiplied by 0.08); 2: constant target `tconst` (DLoss with all-ones/zeros targets).
+ * If count_term != 0 adds 0.005 * #{ targets[i] - (x[i] > 0.3) > 1e-4 } (no gradient).
+ * loss_out[0] = result; partial must hold mgvae_bce_partial_floats() floats.          */
+size_t mgvae_bce_partial_floats(void);
+int mgvae_bce_fwd(const float* x, const float* targets, const float* prior, float tconst, size_t n,
+                  int target_mode, int count_term, float* partial, float* loss_out, void* stream);
+/* dx[i] = gscale[0] * (x - t) / max((1 - x) * x, 1e-12) / n   (torch's BCE backward)   */
+int mgvae_bce_bwd(const float* x, const float* targets, const float* prior, float tconst, size_t n,
+                  int target_mode, const float* gscale, float* dx, void* stream);
+
+/* ---- reparameterisation sampler + KL (old/graphs/models/bar_v1/encoder.py:60-63;
+ * old/graphs/losses/loss.py:14-17).  eps is supplied (mgvae_randn) so tests can pin it.
+ * kl_out[0] = -0.5 * sum(1 + logvar - mean^2 - exp(logvar))                            */
+int mgvae_reparam_kl_fwd(const float* mean, const float* logvar, const float* eps, float* z,
+                         float* partial, float* kl_out, size_t n, void* stream);
+/* dmean = dz + gkl[0]*mean ; dlogvar = dz*eps*0.5*exp(0.5*logvar) + gkl[0]*0.5*(exp(logvar)-1) */
+int mgvae_reparam_kl_bwd(const float* mean, const float* logvar, const float* eps, const float* dz,
+                         const float* gkl, float* dmean, float* dlogvar, size_t n, void* stream);
+
+/* ---- fused flat Adam (torch.optim.Adam defaults, agent/barGen2.py:60-64) ------------
+ * hyper (device, 4 floats): lr/bias_correction1, sqrt(bias_correction2), beta1, beta2.
+ * One launch updates a whole flat parameter buffer; grad_scale multiplies g first
+ * (1/world_size after an all-reduce(sum)).                                             */
+int mgvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
+                    float eps, float grad_scale, void* stream);
+
+/* ---- measurement hooks (bench.py roofline leg) ----------------------------------------
+ * When enabled, every mgvae_conv2d_* launch is bracketed by hipEvents on its stream and
+ * its algorithmic FLOPs are recorded.  mgvae_prof_collect synchronises the events and
+ * returns per-kernel-variant totals: up to `cap` records of
+ * {kind (0 fwd,1 bwd_data,2 bwd_weight), tile id, launches, total ms, total flops}.    */
+typedef struct MgvaeProfRec { int32_t kind, tile, launches; double ms, flops; } MgvaeProfRec;
+int mgvae_prof_enable(int on);
+int mgvae_prof_collect(MgvaeProfRec* out, int cap);
+const char* mgvae_kernel_name(int kind, int tile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGVAE_H */

@@ -1,0 +1,413 @@
+// CBAM (channel attention then spatial attention) fused with the residual + activation
+// that follows it in every block of the reference (graph/cbam.py, graph/encodingBlock.py,
+// graph/decoder.py).  HBM-bound: the feature map u is swept twice in forward (channel
+// pool; spatial pool) plus one apply pass, reductions over H*W use wavefront shuffles
+// (one wave per (n, c) plane) and reductions over C keep pixels on the lanes so every
+// load is coalesced in NCHW.
+//
+//   cg[n,c]  = sigmoid(W2 relu(W1 avg_hw(u)) + W2 relu(W1 max_hw(u)))
+//   v        = u * cg
+//   sg[n,p]  = sigmoid(conv3x3([mean_c v, max_c v]))
+//   o        = v * sg
+//   y        = o                      (mode 0)
+//            = act(u   + o)           (mode 1)
+//            = act(res + o)           (mode 2)
+#include "mgvae_common.h"
+
+struct CbamSave {   // carve-up of the `save` workspace (floats)
+    float *cg, *avg, *mx, *hid, *s_in, *sg;
+    int *amax_hw, *amax_c;
+};
+static __host__ __device__ inline size_t cbam_save_floats(int N, int C, int P) {
+    return (size_t)4 * N * C + (size_t)2 * N * (C / 16) + (size_t)4 * N * P;
+}
+static inline CbamSave carve(float* s, int N, int C, int P) {
+    CbamSave r;
+    const size_t nc = (size_t)N * C, np = (size_t)N * P;
+    r.cg = s; r.avg = s + nc; r.mx = s + 2 * nc; r.amax_hw = reinterpret_cast<int*>(s + 3 * nc);
+    r.hid = s + 4 * nc;
+    float* q = r.hid + (size_t)2 * N * (C / 16);
+    r.s_in = q; r.amax_c = reinterpret_cast<int*>(q + 2 * np); r.sg = q + 3 * np;
+    return r;
+}
+
+// ---------------------------------------------------------------- F1: channel pooling
+__global__ __launch_bounds__(256) void cbam_chan_pool_kernel(const float* __restrict__ u, float* __restrict__ avg,
+                                                             float* __restrict__ mx, int* __restrict__ amax,
+                                                             int NC, int P) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= NC) return;
+    const float* up = u + (size_t)nc * P;
+    float s = 0.f, m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int i = lane; i < P; i += 64) {
+        const float v = up[i];
+        s += v;
+        if (v > m) { m = v; mi = i; }   // strict >: first occurrence wins inside a lane
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+    }
+    if (lane == 0) { avg[nc] = s / (float)P; mx[nc] = m; amax[nc] = mi; }
+}
+
+// ---------------------------------------------------------------- F2: shared MLP + sigmoid
+// one workgroup per sample; dynamic LDS: avg[C], max[C], ha[Cr], hm[Cr]
+__global__ __launch_bounds__(256) void cbam_chan_mlp_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
+                                                            const float* __restrict__ w1, const float* __restrict__ w2,
+                                                            float* __restrict__ hid, float* __restrict__ cg, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cr = C / 16, n = blockIdx.x, tid = threadIdx.x;
+    float* sa = sm; float* sx = sm + C; float* ha = sm + 2 * C; float* hm = ha + Cr;
+    for (int c = tid; c < C; c += 256) { sa[c] = avg[(size_t)n * C + c]; sx[c] = mx[(size_t)n * C + c]; }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < Cr; j += 4) {
+        float a = 0.f, m = 0.f;
+        for (int c = lane; c < C; c += 64) { const float w = w1[(size_t)j * C + c]; a += w * sa[c]; m += w * sx[c]; }
+        a = wave_sum(a); m = wave_sum(m);
+        if (lane == 0) {
+            a = a > 0.f ? a : 0.f; m = m > 0.f ? m : 0.f;
+            ha[j] = a; hm[j] = m;
+            hid[(size_t)n * 2 * Cr + j] = a; hid[(size_t)n * 2 * Cr + Cr + j] = m;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f, m = 0.f;
+        for (int j = 0; j < Cr; ++j) { const float w = w2[(size_t)c * Cr + j]; a += w * ha[j]; m += w * hm[j]; }
+        cg[(size_t)n * C + c] = 1.f / (1.f + expf(-(a + m)));
+    }
+}
+
+// ---------------------------------------------------------------- F3: spatial pooling
+// 64 pixels x 4 channel groups per workgroup; pixels on the lanes (coalesced in NCHW)
+__global__ __launch_bounds__(256) void cbam_spatial_pool_kernel(const float* __restrict__ u, const float* __restrict__ cg,
+                                                                float* __restrict__ s_in, int* __restrict__ amax_c,
+                                                                int N, int C, int P) {
+    __shared__ float ssum[4][64], smax[4][64];
+    __shared__ int sidx[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long gp = (long)blockIdx.x * 64 + lane;
+    const bool ok = gp < (long)N * P;
+    const int n = ok ? (int)(gp / P) : 0, pp = ok ? (int)(gp - (long)n * P) : 0;
+    float s = 0.f, m = -INFINITY;
+    int mi = 0x7fffffff;
+    if (ok) {
+        const float* up = u + (size_t)n * C * P + pp;
+        const float* gp_ = cg + (size_t)n * C;
+        for (int c = grp; c < C; c += 4) {
+            const float v = up[(size_t)c * P] * gp_[c];
+            s += v;
+            if (v > m) { m = v; mi = c; }
+        }
+    }
+    ssum[grp][lane] = s; smax[grp][lane] = m; sidx[grp][lane] = mi;
+    __syncthreads();
+    if (grp == 0 && ok) {
+        float ts = ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
+        float tm = smax[0][lane]; int ti = sidx[0][lane];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) {
+            const float om = smax[g][lane]; const int oi = sidx[g][lane];
+            if (om > tm || (om == tm && oi < ti)) { tm = om; ti = oi; }
+        }
+        s_in[(size_t)n * 2 * P + pp] = ts / (float)C;
+        s_in[(size_t)n * 2 * P + P + pp] = tm;
+        amax_c[(size_t)n * P + pp] = ti;
+    }
+}
+
+// ---------------------------------------------------------------- F4: 3x3 conv (2->1) + sigmoid
+__global__ __launch_bounds__(256) void cbam_spatial_gate_kernel(const float* __restrict__ s_in, const float* __restrict__ wsp,
+                                                                float* __restrict__ sg, int N, int H, int W) {
+    const int P = H * W;
+    const long gp = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gp >= (long)N * P) return;
+    const int n = (int)(gp / P), pp = (int)(gp - (long)n * P);
+    const int h = pp / W, w = pp - h * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const float* sp = s_in + ((size_t)n * 2 + ch) * P;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+            if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w + kw - 1;
+                if ((unsigned)ww >= (unsigned)W) continue;
+                acc += sp[hh * W + ww] * wsp[ch * 9 + kh * 3 + kw];
+            }
+        }
+    }
+    sg[gp] = 1.f / (1.f + expf(-acc));
+}
+
+// ---------------------------------------------------------------- F5: apply + residual + act
+__global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict__ u, const float* __restrict__ res,
+                                                         const float* __restrict__ cg, const float* __restrict__ sg,
+                                                         float* __restrict__ y, int N, int C, int P, int y_ctot,
+                                                         int y_coff, int mode, int act, float slope) {
+    const long total = (long)N * C * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int nc = (int)(i / P), pp = (int)(i - (long)nc * P);
+        const int n = nc / C, c = nc - n * C;
+        const float uu = u[i];
+        const float o = (uu * cg[nc]) * sg[(size_t)n * P + pp];
+        float v;
+        if (mode == 0) v = o;
+        else if (mode == 1) v = apply_act(uu + o, act, slope);
+        else v = apply_act(res[i] + o, act, slope);
+        y[((size_t)n * y_ctot + y_coff + c) * P + pp] = v;
+    }
+}
+
+// ================================================================ backward
+// B1: dt[n,p] = (sum_c g * u * cg) * sg * (1 - sg),  g = dy * act'(y)
+__global__ __launch_bounds__(256) void cbam_bwd_spatial_kernel(const float* __restrict__ u, const float* __restrict__ y,
+                                                               const float* __restrict__ dy, const float* __restrict__ cg,
+                                                               const float* __restrict__ sg, float* __restrict__ dt,
+                                                               int N, int C, int P, int y_ctot, int y_coff, int mode,
+                                                               int act, float slope) {
+    __shared__ float ssum[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long gp = (long)blockIdx.x * 64 + lane;
+    const bool ok = gp < (long)N * P;
+    const int n = ok ? (int)(gp / P) : 0, pp = ok ? (int)(gp - (long)n * P) : 0;
+    float s = 0.f;
+    if (ok) {
+        const float* up = u + (size_t)n * C * P + pp;
+        const float* yp = y + ((size_t)n * y_ctot + y_coff) * P + pp;
+        const float* dyp = dy + ((size_t)n * y_ctot + y_coff) * P + pp;
+        const float* gp_ = cg + (size_t)n * C;
+        for (int c = grp; c < C; c += 4) {
+            float g = dyp[(size_t)c * P];
+            if (mode != 0) g *= act_grad_from_out(yp[(size_t)c * P], act, slope);
+            s += g * (up[(size_t)c * P] * gp_[c]);
+        }
+    }
+    ssum[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && ok) {
+        const float t = ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
+        const float sgg = sg[gp];
+        dt[gp] = t * sgg * (1.f - sgg);
+    }
+}
+
+// B2: ds_in = conv_transpose3x3(dt, wsp); dwsp += corr(s_in, dt)
+__global__ __launch_bounds__(256) void cbam_bwd_sgate_kernel(const float* __restrict__ dt, const float* __restrict__ s_in,
+                                                             const float* __restrict__ wsp, float* __restrict__ ds_in,
+                                                             float* __restrict__ dwsp, int N, int H, int W) {
+    __shared__ float red[4][18];
+    const int P = H * W;
+    const long gp = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = gp < (long)N * P;
+    float dw[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) dw[i] = 0.f;
+    if (ok) {
+        const int n = (int)(gp / P), pp = (int)(gp - (long)n * P);
+        const int h = pp / W, w = pp - h * W;
+        const float* dtp = dt + (size_t)n * P;
+        const float mydt = dtp[pp];
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                // gradient wrt s_in[h][w]: outputs at (h+1-kh, w+1-kw) used tap (kh,kw) on it
+                const int oh = h + 1 - kh, ow = w + 1 - kw;
+                if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
+                    const float t = dtp[oh * W + ow];
+                    d0 += t * wsp[kh * 3 + kw];
+                    d1 += t * wsp[9 + kh * 3 + kw];
+                }
+                // weight gradient: output (h,w) read s_in at (h+kh-1, w+kw-1)
+                const int ih = h + kh - 1, iw = w + kw - 1;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    dw[kh * 3 + kw] += mydt * s_in[((size_t)n * 2) * P + ih * W + iw];
+                    dw[9 + kh * 3 + kw] += mydt * s_in[((size_t)n * 2 + 1) * P + ih * W + iw];
+                }
+            }
+        }
+        ds_in[((size_t)n * 2) * P + pp] = d0;
+        ds_in[((size_t)n * 2 + 1) * P + pp] = d1;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        const float s = wave_sum(dw[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 18 && dwsp)
+        atomicAdd(&dwsp[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// B3: per (n,c) plane: dv, dcg, du (without the channel-pool terms), dres
+__global__ __launch_bounds__(256) void cbam_bwd_channel_kernel(
+    const float* __restrict__ u, const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ cg,
+    const float* __restrict__ sg, const float* __restrict__ ds_in, const int* __restrict__ amax_c,
+    float* __restrict__ du, float* __restrict__ dres, float* __restrict__ dcg, int N, int C, int P, int y_ctot,
+    int y_coff, int mode, int act, float slope) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= N * C) return;
+    const int n = nc / C, c = nc - n * C;
+    const float* up = u + (size_t)nc * P;
+    const float* yp = y + ((size_t)n * y_ctot + y_coff + c) * P;
+    const float* dyp = dy + ((size_t)n * y_ctot + y_coff + c) * P;
+    const float* sgp = sg + (size_t)n * P;
+    const float* dmean = ds_in + (size_t)n * 2 * P;
+    const float* dmax = dmean + P;
+    const int* amp = amax_c + (size_t)n * P;
+    const float g_c = cg[nc], invC = 1.f / (float)C;
+    float acc = 0.f;
+    for (int i = lane; i < P; i += 64) {
+        float g = dyp[i];
+        if (mode != 0) g *= act_grad_from_out(yp[i], act, slope);
+        float dv = g * sgp[i] + dmean[i] * invC;
+        if (amp[i] == c) dv += dmax[i];
+        acc += dv * up[i];
+        du[(size_t)nc * P + i] = dv * g_c + (mode == 1 ? g : 0.f);
+        if (mode == 2) dres[(size_t)nc * P + i] = g;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dcg[nc] = acc;
+}
+
+// B4: MLP backward, one workgroup per sample.  dynamic LDS: dpre[C], ha,hm,dha,dhm[Cr]
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restrict__ dcg, const float* __restrict__ cg,
+                                                           const float* __restrict__ hid, const float* __restrict__ avg,
+                                                           const float* __restrict__ mx, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, float* __restrict__ dw1,
+                                                           float* __restrict__ dw2, float* __restrict__ davg,
+                                                           float* __restrict__ dmaxp, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Cr = C / 16, n = blockIdx.x, tid = threadIdx.x;
+    float* dpre = sm; float* ha = sm + C; float* hm = ha + Cr; float* dha = hm + Cr; float* dhm = dha + Cr;
+    for (int c = tid; c < C; c += 256) {
+        const float g = cg[(size_t)n * C + c];
+        dpre[c] = dcg[(size_t)n * C + c] * g * (1.f - g);
+    }
+    for (int j = tid; j < Cr; j += 256) { ha[j] = hid[(size_t)n * 2 * Cr + j]; hm[j] = hid[(size_t)n * 2 * Cr + Cr + j]; }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < Cr; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += w2[(size_t)c * Cr + j] * dpre[c];
+        s = wave_sum(s);
+        if (lane == 0) { dha[j] = ha[j] > 0.f ? s : 0.f; dhm[j] = hm[j] > 0.f ? s : 0.f; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float da = 0.f, dm = 0.f;
+        for (int j = 0; j < Cr; ++j) {
+            const float w = w1[(size_t)j * C + c];
+            da += w * dha[j]; dm += w * dhm[j];
+        }
+        davg[(size_t)n * C + c] = da; dmaxp[(size_t)n * C + c] = dm;
+    }
+    // weight gradients: flat index on the lanes so each atomic wave-instruction is 256 contiguous bytes
+    const int tot = C * Cr;
+    if (dw1)
+        for (int f = tid; f < tot; f += 256) {
+            const int j = f / C, c = f - j * C;
+            atomicAdd(&dw1[f], dha[j] * avg[(size_t)n * C + c] + dhm[j] * mx[(size_t)n * C + c]);
+        }
+    if (dw2)
+        for (int f = tid; f < tot; f += 256) {
+            const int c = f / Cr, j = f - c * Cr;
+            atomicAdd(&dw2[f], dpre[c] * (ha[j] + hm[j]));
+        }
+}
+
+// B5: du += davg/P + [p == argmax_hw] dmaxp
+__global__ __launch_bounds__(256) void cbam_bwd_finish_kernel(float* __restrict__ du, const float* __restrict__ davg,
+                                                              const float* __restrict__ dmaxp, const int* __restrict__ amax_hw,
+                                                              long total, int P) {
+    const float invP = 1.f / (float)P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int nc = (int)(i / P), pp = (int)(i - (long)nc * P);
+        float v = du[i] + davg[nc] * invP;
+        if (amax_hw[nc] == pp) v += dmaxp[nc];
+        du[i] = v;
+    }
+}
+
+// ================================================================ host entry points
+extern "C" size_t mgvae_cbam_save_floats(int N, int C, int H, int W) { return cbam_save_floats(N, C, H * W); }
+extern "C" size_t mgvae_cbam_bwd_scratch_floats(int N, int C, int H, int W) {
+    return (size_t)3 * N * H * W + (size_t)3 * N * C;
+}
+
+static int cbam_check(int N, int C, int H, int W, int ctot, int coff, int mode, int act) {
+    if (N <= 0 || C < 16 || (C % 16) != 0 || C > 4096 || H <= 0 || W <= 0) return MGVAE_EINVAL;
+    if (coff < 0 || coff + C > ctot || mode < 0 || mode > 2) return MGVAE_EINVAL;
+    if (act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
+    if ((long)N * C * H * W >= (1L << 31)) return MGVAE_EINVAL;
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1, const float* w2, const float* wsp,
+                              float* y, float* save, int N, int C, int H, int W, int y_ctot, int y_coff, int mode,
+                              int act, float slope, void* stream) {
+    int rc = cbam_check(N, C, H, W, y_ctot, y_coff, mode, act);
+    if (rc) return rc;
+    if (!u || !w1 || !w2 || !wsp || !y || !save || (mode == 2 && !res)) return MGVAE_EINVAL;
+    hipStream_t s = as_stream(stream);
+    const int P = H * W, NC = N * C, Cr = C / 16;
+    CbamSave sv = carve(save, N, C, P);
+    hipLaunchKernelGGL(cbam_chan_pool_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, sv.avg, sv.mx, sv.amax_hw, NC, P);
+    hipLaunchKernelGGL(cbam_chan_mlp_kernel, dim3(N), dim3(256), (2 * C + 2 * Cr) * sizeof(float), s, sv.avg, sv.mx,
+                       w1, w2, sv.hid, sv.cg, C);
+    hipLaunchKernelGGL(cbam_spatial_pool_kernel, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, sv.cg, sv.s_in,
+                       sv.amax_c, N, C, P);
+    hipLaunchKernelGGL(cbam_spatial_gate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, sv.s_in, wsp, sv.sg, N, H, W);
+    const long total = (long)NC * P;
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3(blocks), dim3(256), 0, s, u, res, sv.cg, sv.sg, y, N, C, P, y_ctot,
+                       y_coff, mode, act, slope);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, const float* w1, const float* w2,
+                              const float* wsp, const float* save, float* du, float* dres, float* dw1, float* dw2,
+                              float* dwsp, float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff,
+                              int mode, int act, float slope, void* stream) {
+    int rc = cbam_check(N, C, H, W, y_ctot, y_coff, mode, act);
+    if (rc) return rc;
+    if (!u || !y || !dy || !w1 || !w2 || !wsp || !save || !du || !scratch || (mode == 2 && !dres)) return MGVAE_EINVAL;
+    hipStream_t s = as_stream(stream);
+    const int P = H * W, NC = N * C, Cr = C / 16;
+    CbamSave sv = carve(const_cast<float*>(save), N, C, P);
+    float* dt = scratch;                         // [N,P]
+    float* ds_in = scratch + (size_t)N * P;      // [N,2,P]
+    float* dcg = scratch + (size_t)3 * N * P;    // [N,C]
+    float* davg = dcg + NC;
+    float* dmaxp = davg + NC;
+    hipLaunchKernelGGL(cbam_bwd_spatial_kernel, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt,
+                       N, C, P, y_ctot, y_coff, mode, act, slope);
+    hipLaunchKernelGGL(cbam_bwd_sgate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, dt, sv.s_in, wsp, ds_in,
+                       dwsp, N, H, W);
+    hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
+                       sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
+    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(N), dim3(256), (C + 4 * Cr) * sizeof(float), s, dcg, sv.cg, sv.hid,
+                       sv.avg, sv.mx, w1, w2, dw1, dw2, davg, dmaxp, C);
+    const long total = (long)NC * P;
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    hipLaunchKernelGGL(cbam_bwd_finish_kernel, dim3(blocks), dim3(256), 0, s, du, davg, dmaxp, sv.amax_hw, total, P);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}

@@ -1,0 +1,530 @@
+// Implicit-GEMM convolution family for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32): Conv2d forward, Conv2d data-gradient == ConvTranspose2d
+// forward (stride-phase decomposed so no zero taps are multiplied), and the weight
+// gradient (split-K over pixels, fp32 atomics into the caller-zeroed gradient).
+//
+// One workgroup = 256 threads = 4 waves arranged 2x2; wave (wi, wj) owns TI x TJ MFMA
+// tiles of 32x32, so the workgroup tile is (64*TI) x (64*TJ).  The MFMA "column" (lane)
+// index always runs along the memory-contiguous axis of the written tensor (pixels for
+// activations, (cx,kh,kw) for weight gradients) so every accumulator register stores as
+// two 128-byte segments.  Operand tiles are staged global -> registers -> LDS with a
+// two-deep LDS ring; the gather loaders keep the K index wave-uniform so tap decode is
+// done once per wave-instruction, and LDS images are laid out so both the staging
+// writes and the MFMA fragment reads (ds_read_b32, lanes 0-31 / 32-63) are
+// conflict-free.
+#include "mgvae_common.h"
+#include <mutex>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 16
+#define LDP (BK + 1)   // padded row length of the "row-major, k fastest" LDS images
+
+struct IgemmP {
+    const float* X;     // image-side tensor  [N, x_ctot, H, W]
+    const float* Y;     // feature-side tensor [N, y_ctot, OH, OW]
+    const float* Wt;    // [Cy, Cx, KH, KW]
+    const float* bias;  // fwd: [Cy]; bwd_data: [Cx]; may be null
+    float* out;         // fwd: Y; bwd_data: X; bwd_weight: dWt
+    int N, Cx, H, W, Cy, OH, OW, KH, KW, SH, SW, PH, PW;
+    int x_ctot, x_coff, y_ctot, y_coff;
+    int act;
+    float slope;
+    int kchunk;         // bwd_weight: pixels per split
+};
+
+enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
+
+// ---------------------------------------------------------------------------------------
+// MFMA over one staged K-tile.  A image: A_IK ? As[i][LDP] : As[k][IT];
+//                               B image: B_KJ ? Bs[k][JT]  : Bs[j][LDP].
+template <int TI, int TJ, bool A_IK, bool B_KJ>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
+                                         f32x16 (&acc)[TI][TJ], int wi, int wj, int l31, int h) {
+    constexpr int IT = 64 * TI, JT = 64 * TJ;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        const int k = 2 * kk + h;
+        float a[TI], b[TJ];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) {
+            const int i = wi * 32 * TI + ti * 32 + l31;
+            a[ti] = A_IK ? As[i * LDP + k] : As[k * IT + i];
+        }
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+            const int j = wj * 32 * TJ + tj * 32 + l31;
+            b[tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDP + k];
+        }
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < TJ; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+}
+
+// Running decode of a K index that enumerates (channel, tap): advance by `step`.
+struct ChanTap {
+    int c, t;
+    __device__ __forceinline__ void init(int k, int T) { c = k / T; t = k - c * T; }
+    __device__ __forceinline__ void advance(int step, int T) {
+        t += step;
+        while (t >= T) { t -= T; ++c; }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+template <int MODE, int TI, int TJ>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
+    constexpr int IT = 64 * TI, JT = 64 * TJ;
+    constexpr bool A_IK = (MODE != MODE_BWD_DATA);   // weights [cy][k] / dY [cy][pix]: k contiguous
+    constexpr bool B_KJ = (MODE != MODE_BWD_WEIGHT); // gathers with pixels along lanes
+    constexpr int A_ELEMS = A_IK ? IT * LDP : BK * IT;
+    constexpr int B_ELEMS = B_KJ ? BK * JT : JT * LDP;
+    constexpr int NA = IT * BK / 256, NB = JT * BK / 256;
+
+    __shared__ float lds[2 * (A_ELEMS + B_ELEMS)];
+    __shared__ int tap_off[16];   // source offset of a tap
+    __shared__ int tap_dh[16], tap_dw[16];
+    __shared__ int tap_w[16];     // bwd_data: offset of the tap inside a KHxKW weight slice
+    float* As0 = lds;
+    float* Bs0 = lds + 2 * A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.y * IT, j0 = blockIdx.x * JT;
+
+    const int HW = p.H * p.W, P = p.OH * p.OW;
+
+    // ---------------- per-mode problem shape + tap tables ------------------------------
+    int Itot, Jtot, kbeg, kend, T;
+    // bwd_data phase constants
+    int rh = 0, rw = 0, Wb = 1, Pp = 1;
+    if constexpr (MODE == MODE_FWD) {
+        Itot = p.Cy; Jtot = p.N * P; T = p.KH * p.KW; kbeg = 0; kend = p.Cx * T;
+        if (tid < T) {
+            const int kh = tid / p.KW, kw = tid - kh * p.KW;
+            tap_dh[tid] = kh; tap_dw[tid] = kw; tap_off[tid] = kh * p.W + kw;
+        }
+    } else if constexpr (MODE == MODE_BWD_DATA) {
+        const int ph = blockIdx.z;
+        rh = ph / p.SW; rw = ph - rh * p.SW;
+        const int kh0 = (rh + p.PH) % p.SH, kw0 = (rw + p.PW) % p.SW;
+        const int nkh = kh0 < p.KH ? (p.KH - kh0 + p.SH - 1) / p.SH : 0;
+        const int nkw = kw0 < p.KW ? (p.KW - kw0 + p.SW - 1) / p.SW : 0;
+        const int qh = (rh + p.PH - kh0) / p.SH, qw = (rw + p.PW - kw0) / p.SW;
+        const int Ha = rh < p.H ? (p.H - rh + p.SH - 1) / p.SH : 0;
+        Wb = rw < p.W ? (p.W - rw + p.SW - 1) / p.SW : 0;
+        Pp = Ha * Wb;
+        Itot = p.Cx; Jtot = p.N * Pp; T = nkh * nkw; kbeg = 0; kend = p.Cy * T;
+        if (Jtot == 0 || j0 >= Jtot) return;   // uniform across the workgroup
+        if (tid < T) {
+            const int jh = tid / nkw, jw = tid - jh * nkw;
+            tap_dh[tid] = qh - jh; tap_dw[tid] = qw - jw;
+            tap_off[tid] = (qh - jh) * p.OW + (qw - jw);
+            tap_w[tid] = (kh0 + p.SH * jh) * p.KW + kw0 + p.SW * jw;
+        }
+        if (T == 0) T = 1;   // kend == 0: loop never runs, keep divisions defined
+    } else {
+        Itot = p.Cy; Jtot = p.Cx * p.KH * p.KW; T = 1;
+        kbeg = blockIdx.z * p.kchunk;
+        kend = min(p.N * P, kbeg + p.kchunk);
+    }
+    __syncthreads();
+
+    // ---------------- loader state ------------------------------------------------------
+    // "lanes along j/i" mapping (KJ / KI images): each wave-instruction covers 64 columns
+    // of one K row; the K row is wave-uniform.
+    constexpr int JC = JT / 64, IC = IT / 64;
+    const int jc = wave % JC, jkr0 = wave / JC;   constexpr int jkstep = 4 / JC;
+    const int ic = wave % IC, ikr0 = wave / IC;   constexpr int ikstep = 4 / IC;
+    // "lanes along k" mapping (IK / JK images): 16 lanes per row, 16 rows per pass.
+    const int kl = tid & 15, rr = tid >> 4;
+
+    // B gather state (FWD: from X; BWD_DATA: from Y)
+    bool bj_valid = false; int b_pix = 0, b_r0 = 0, b_c0 = 0, b_RH = 1, b_RW = 1, b_cstride = 0;
+    ChanTap bk; bk.c = 0; bk.t = 0;
+    // A gather state (BWD_DATA weights)
+    ChanTap ak; ak.c = 0; ak.t = 0;
+    bool ai_valid = false; int a_i = 0;
+    // BWD_WEIGHT state
+    int w_n = 0, w_p = 0;                      // running pixel of this thread's k lane
+    int bj_off[NB], bj_dh[NB], bj_dw[NB];      // per-row (cx,kh,kw) constants
+    (void)bj_off; (void)bj_dh; (void)bj_dw;
+
+    if constexpr (MODE == MODE_FWD) {
+        const int j = j0 + jc * 64 + lane;
+        bj_valid = j < Jtot;
+        const int jj = bj_valid ? j : 0;
+        const int n = jj / P, pp = jj - n * P;
+        const int oh = pp / p.OW, ow = pp - oh * p.OW;
+        b_r0 = oh * p.SH - p.PH; b_c0 = ow * p.SW - p.PW;
+        b_pix = (n * p.x_ctot + p.x_coff) * HW + b_r0 * p.W + b_c0;
+        b_RH = p.H; b_RW = p.W; b_cstride = HW;
+        bk.init(jkr0, T);
+    } else if constexpr (MODE == MODE_BWD_DATA) {
+        const int j = j0 + jc * 64 + lane;
+        bj_valid = j < Jtot;
+        const int jj = bj_valid ? j : 0;
+        const int n = jj / Pp, pp = jj - n * Pp;
+        const int a = pp / Wb, b = pp - a * Wb;
+        b_r0 = a; b_c0 = b;
+        b_pix = (n * p.y_ctot + p.y_coff) * P + a * p.OW + b;
+        b_RH = p.OH; b_RW = p.OW; b_cstride = P;
+        bk.init(jkr0, T);
+        a_i = i0 + ic * 64 + lane;
+        ai_valid = a_i < Itot;
+        ak.init(ikr0, T);
+    } else {
+        const int kp = kbeg + kl;
+        w_n = kp / P; w_p = kp - w_n * P;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            const int gj = j0 + rr + 16 * r;
+            if (gj < Jtot) {
+                const int KK = p.KH * p.KW;
+                const int cx = gj / KK, t = gj - cx * KK;
+                const int kh = t / p.KW, kw = t - kh * p.KW;
+                bj_dh[r] = kh - p.PH; bj_dw[r] = kw - p.PW;
+                bj_off[r] = cx * HW + (kh - p.PH) * p.W + (kw - p.PW);
+            } else {
+                bj_dh[r] = -(1 << 28); bj_dw[r] = 0; bj_off[r] = 0;   // never in range
+            }
+        }
+    }
+
+    float ra[NA], rb[NB];
+
+    auto load_tile = [&](int k0) {
+        // ------------------------------ A operand ------------------------------
+        if constexpr (MODE == MODE_FWD) {
+            const int K = kend;
+            const int gk = k0 + kl;
+#pragma unroll
+            for (int r = 0; r < NA; ++r) {
+                const int gi = i0 + rr + 16 * r;
+                ra[r] = (gi < Itot && gk < K) ? p.Wt[(size_t)gi * K + gk] : 0.f;
+            }
+        } else if constexpr (MODE == MODE_BWD_DATA) {
+            const int KK = p.KH * p.KW;
+#pragma unroll
+            for (int r = 0; r < NA; ++r) {
+                const int k = k0 + ikr0 + ikstep * r;
+                const bool ok = ai_valid && k < kend;
+                ra[r] = ok ? p.Wt[((size_t)ak.c * p.Cx + a_i) * KK + tap_w[ak.t]] : 0.f;
+                ak.advance(ikstep, T);
+            }
+        } else {
+            const bool kok = (k0 + kl) < kend;
+            const int base = (w_n * p.y_ctot + p.y_coff) * P + w_p;
+#pragma unroll
+            for (int r = 0; r < NA; ++r) {
+                const int gi = i0 + rr + 16 * r;
+                ra[r] = (kok && gi < Itot) ? p.Y[base + gi * P] : 0.f;
+            }
+        }
+        // ------------------------------ B operand ------------------------------
+        if constexpr (MODE != MODE_BWD_WEIGHT) {
+            const float* __restrict__ src = (MODE == MODE_FWD) ? p.X : p.Y;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int k = k0 + jkr0 + jkstep * r;
+                const int t = bk.t;
+                const bool ok = bj_valid && k < kend &&
+                                (unsigned)(b_r0 + tap_dh[t]) < (unsigned)b_RH &&
+                                (unsigned)(b_c0 + tap_dw[t]) < (unsigned)b_RW;
+                rb[r] = ok ? src[b_pix + bk.c * b_cstride + tap_off[t]] : 0.f;
+                bk.advance(jkstep, T);
+            }
+        } else {
+            const bool kok = (k0 + kl) < kend;
+            const int oh = w_p / p.OW, ow = w_p - oh * p.OW;
+            const int r0 = oh * p.SH, c0 = ow * p.SW;
+            const int base = (w_n * p.x_ctot + p.x_coff) * HW + r0 * p.W + c0;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const bool ok = kok && (unsigned)(r0 + bj_dh[r]) < (unsigned)p.H &&
+                                (unsigned)(c0 + bj_dw[r]) < (unsigned)p.W;
+                rb[r] = ok ? p.X[base + bj_off[r]] : 0.f;
+            }
+            // advance this thread's pixel by one K tile
+            w_p += BK;
+            while (w_p >= P) { w_p -= P; ++w_n; }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = As0 + buf * A_ELEMS;
+        float* Bs = Bs0 + buf * B_ELEMS;
+        if constexpr (A_IK) {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) As[(rr + 16 * r) * LDP + kl] = ra[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) As[(ikr0 + ikstep * r) * IT + ic * 64 + lane] = ra[r];
+        }
+        if constexpr (B_KJ) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) Bs[(jkr0 + jkstep * r) * JT + jc * 64 + lane] = rb[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) Bs[(rr + 16 * r) * LDP + kl] = rb[r];
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    if (nt > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) load_tile(kbeg + (t + 1) * BK);
+            mma_tile<TI, TJ, A_IK, B_KJ>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, wi, wj, l31, h);
+            if (t + 1 < nt) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue -----------------------------------------------------------
+    // D row (i) = (reg&3) + 8*(reg>>2) + 4*h ; D col (j) = lane&31
+    if constexpr (MODE == MODE_BWD_WEIGHT) {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+            const int gj = j0 + wj * 32 * TJ + tj * 32 + l31;
+            if (gj >= Jtot) continue;
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = i0 + wi * 32 * TI + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (gi < Itot) atomicAdd(&p.out[(size_t)gi * Jtot + gj], acc[ti][tj][r]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+            const int gj = j0 + wj * 32 * TJ + tj * 32 + l31;
+            if (gj >= Jtot) continue;
+            int obase, cstride;
+            if constexpr (MODE == MODE_FWD) {
+                const int n = gj / P, pp = gj - n * P;
+                obase = (n * p.y_ctot + p.y_coff) * P + pp; cstride = P;
+            } else {
+                const int n = gj / Pp, pp = gj - n * Pp;
+                const int a = pp / Wb, b = pp - a * Wb;
+                obase = (n * p.x_ctot + p.x_coff) * HW + (rh + p.SH * a) * p.W + rw + p.SW * b;
+                cstride = HW;
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = i0 + wi * 32 * TI + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (gi < Itot) {
+                        float v = acc[ti][tj][r];
+                        if (p.bias) v += p.bias[gi];
+                        p.out[obase + gi * cstride] = apply_act(v, p.act, p.slope);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+static int g_cus = 256;
+static bool g_prof = false;
+struct ProfEntry { int kind, tile; double flops; hipEvent_t e0, e1; };
+static std::vector<ProfEntry> g_prof_entries;
+static std::mutex g_prof_mu;
+
+static int validate(const MgvaeConvDesc* d) {
+    if (!d) return MGVAE_EINVAL;
+    if (d->N <= 0 || d->Cx <= 0 || d->Cy <= 0 || d->H <= 0 || d->W <= 0 || d->OH <= 0 || d->OW <= 0) return MGVAE_EINVAL;
+    if (d->KH <= 0 || d->KW <= 0 || d->SH <= 0 || d->SW <= 0 || d->PH < 0 || d->PW < 0) return MGVAE_EINVAL;
+    if (d->KH * d->KW > 16) return MGVAE_EINVAL;
+    if ((d->H + 2 * d->PH - d->KH) / d->SH + 1 != d->OH) return MGVAE_EINVAL;
+    if ((d->W + 2 * d->PW - d->KW) / d->SW + 1 != d->OW) return MGVAE_EINVAL;
+    if (d->x_coff < 0 || d->x_coff + d->Cx > d->x_ctot) return MGVAE_EINVAL;
+    if (d->y_coff < 0 || d->y_coff + d->Cy > d->y_ctot) return MGVAE_EINVAL;
+    const long xe = (long)d->N * d->x_ctot * d->H * d->W, ye = (long)d->N * d->y_ctot * d->OH * d->OW;
+    if (xe >= (1L << 31) || ye >= (1L << 31) || (long)d->Cx * d->Cy * d->KH * d->KW >= (1L << 31)) return MGVAE_EINVAL;
+    return MGVAE_OK;
+}
+
+static IgemmP make_params(const MgvaeConvDesc* d) {
+    IgemmP p{};
+    p.N = d->N; p.Cx = d->Cx; p.H = d->H; p.W = d->W; p.Cy = d->Cy; p.OH = d->OH; p.OW = d->OW;
+    p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
+    p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
+    p.act = d->act; p.slope = d->slope; p.kchunk = 0;
+    return p;
+}
+
+// tile ids: 0 = 128x128, 1 = 64(i)x128(j), 2 = 128(i)x64(j), 3 = 64x64
+static int pick_tile(long Itot, long Jtot, int Z) {
+    int ti = Itot > 64 ? 2 : 1, tj = Jtot > 64 ? 2 : 1;
+    auto wgs = [&](int a, int b) { return (long)cdiv(Itot, 64 * a) * cdiv(Jtot, 64 * b) * Z; };
+    const long want = (long)g_cus * 3 / 2;
+    if (wgs(ti, tj) < want && tj == 2) tj = 1;
+    if (wgs(ti, tj) < want && ti == 2) ti = 1;
+    return (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
+}
+
+template <int MODE>
+static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
+    switch (tile) {
+        case 0: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 2>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 1>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 1>), grid, dim3(256), 0, s, p); break;
+    }
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+template <int MODE>
+static int run(int tile, dim3 grid, const IgemmP& p, hipStream_t s, double flops) {
+    if (!g_prof) return launch<MODE>(tile, grid, p, s);
+    ProfEntry pe{MODE, tile, flops, nullptr, nullptr};
+    if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess) return MGVAE_ELAUNCH;
+    hipEventRecord(pe.e0, s);
+    int rc = launch<MODE>(tile, grid, p, s);
+    hipEventRecord(pe.e1, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_entries.push_back(pe);
+    return rc;
+}
+
+extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
+                                float* y, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return MGVAE_EINVAL;
+    IgemmP p = make_params(d);
+    p.X = x; p.Wt = w; p.bias = bias; p.out = y; p.Y = nullptr;
+    const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
+    const int tile = pick_tile(I, J, 1);
+    const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
+    dim3 grid(cdiv(J, jt), cdiv(I, it), 1);
+    return run<MODE_FWD>(tile, grid, p, as_stream(stream), 2.0 * I * J * d->Cx * d->KH * d->KW);
+}
+
+extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
+                                     float* x, void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return MGVAE_EINVAL;
+    IgemmP p = make_params(d);
+    p.Y = y; p.Wt = w; p.bias = bias; p.out = x; p.X = nullptr;
+    const int Z = d->SH * d->SW;
+    const long I = d->Cx;
+    const long J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
+    const int tile = pick_tile(I, J, Z);
+    const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
+    dim3 grid(cdiv(J, jt), cdiv(I, it), Z);
+    // algorithmic flops: every (output pixel, tap) pair that exists = same as the forward conv
+    const double flops = 2.0 * d->Cy * d->Cx * d->KH * d->KW * (double)d->N * d->OH * d->OW;
+    return run<MODE_BWD_DATA>(tile, grid, p, as_stream(stream), flops);
+}
+
+extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
+                                       void* stream) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!x || !dw || !y) return MGVAE_EINVAL;
+    IgemmP p = make_params(d);
+    p.X = x; p.Y = y; p.out = dw; p.Wt = nullptr; p.bias = nullptr;
+    const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
+    int ti = I > 64 ? 2 : 1, tj = J > 64 ? 2 : 1;
+    long tiles = (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj);
+    if (tiles < g_cus && tj == 2) { tj = 1; tiles = (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); }
+    if (tiles < g_cus && ti == 2) { ti = 1; tiles = (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); }
+    const int tile = (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
+    long splits = cdiv((long)g_cus * 3, tiles);
+    const long max_splits = cdiv(M, BK * 8);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long kchunk = cdiv(M, splits);
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    splits = cdiv(M, kchunk);
+    p.kchunk = (int)kchunk;
+    dim3 grid(cdiv(J, 64 * tj), cdiv(I, 64 * ti), (unsigned)splits);
+    return run<MODE_BWD_WEIGHT>(tile, grid, p, as_stream(stream), 2.0 * I * J * M);
+}
+
+extern "C" int mgvae_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof = on != 0;
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    MgvaeProfRec recs[12];
+    for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < 4; ++t) recs[k * 4 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
+    for (auto& pe : g_prof_entries) {
+        float ms = 0.f;
+        hipEventSynchronize(pe.e1);
+        hipEventElapsedTime(&ms, pe.e0, pe.e1);
+        MgvaeProfRec& r = recs[pe.kind * 4 + pe.tile];
+        r.launches += 1; r.ms += ms; r.flops += pe.flops;
+        hipEventDestroy(pe.e0); hipEventDestroy(pe.e1);
+    }
+    g_prof_entries.clear();
+    int n = 0;
+    for (int i = 0; i < 12 && n < cap; ++i)
+        if (recs[i].launches > 0) out[n++] = recs[i];
+    return n;
+}
+
+extern "C" const char* mgvae_kernel_name(int kind, int tile) {
+    static const char* names[12] = {
+        "igemm_kernel<0, 2, 2>", "igemm_kernel<0, 1, 2>", "igemm_kernel<0, 2, 1>", "igemm_kernel<0, 1, 1>",
+        "igemm_kernel<1, 2, 2>", "igemm_kernel<1, 1, 2>", "igemm_kernel<1, 2, 1>", "igemm_kernel<1, 1, 1>",
+        "igemm_kernel<2, 2, 2>", "igemm_kernel<2, 1, 2>", "igemm_kernel<2, 2, 1>", "igemm_kernel<2, 1, 1>"};
+    if (kind < 0 || kind > 2 || tile < 0 || tile > 3) return "?";
+    return names[kind * 4 + tile];
+}
+
+extern "C" int mgvae_device_info(char* arch, size_t arch_len, int* cu_count) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MGVAE_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return MGVAE_ENODEV;
+    if (arch && arch_len) {
+        size_t i = 0;
+        for (; i + 1 < arch_len && prop.gcnArchName[i]; ++i) arch[i] = prop.gcnArchName[i];
+        arch[i] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
+    return MGVAE_OK;
+}
+
+extern "C" const char* mgvae_strerror(int code) {
+    switch (code) {
+        case MGVAE_OK: return "ok";
+        case MGVAE_EINVAL: return "invalid argument or unsupported geometry";
+        case MGVAE_ELAUNCH: return "kernel launch failed";
+        case MGVAE_ENODEV: return "no usable gfx950 device";
+        default: return "unknown error";
+    }
+}

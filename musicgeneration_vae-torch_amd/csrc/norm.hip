@@ -1,0 +1,155 @@
+// InstanceNorm2d (affine, biased variance, no running statistics) with a fused
+// activation, its backward, whole-map average pooling and the bias-gradient reduction.
+// All are HBM-bound: one 64-lane wave owns one (sample, channel) plane, reads are
+// lane-contiguous, reductions are wavefront shuffles (no LDS round trip).
+#include "mgvae_common.h"
+
+// ------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void instance_norm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ stats, int NC, int C, int P, int y_ctot, int y_coff,
+    float eps, int act, float slope) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= NC) return;
+    const int n = nc / C, c = nc - n * C;
+    const float* xp = x + (size_t)nc * P;
+    float s = 0.f;
+    for (int i = lane; i < P; i += 64) s += xp[i];
+    const float mean = wave_sum(s) / (float)P;
+    float v = 0.f;
+    for (int i = lane; i < P; i += 64) { const float d = xp[i] - mean; v += d * d; }
+    const float var = wave_sum(v) / (float)P;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
+    const float g = gamma[c], b = beta[c];
+    float* yp = y + ((size_t)n * y_ctot + y_coff + c) * P;
+    for (int i = lane; i < P; i += 64) yp[i] = apply_act((xp[i] - mean) * rstd * g + b, act, slope);
+}
+
+// ------------------------------------------------------------------------ backward
+__global__ __launch_bounds__(256) void instance_norm_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stats, const float* __restrict__ dy, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int C, int P, int dy_ctot, int dy_coff,
+    int act, float slope) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= NC) return;
+    const int n = nc / C, c = nc - n * C;
+    const float* xp = x + (size_t)nc * P;
+    const float* dyp = dy + ((size_t)n * dy_ctot + dy_coff + c) * P;
+    float* dxp = dx + (size_t)nc * P;
+    const float mean = stats[2 * nc], rstd = stats[2 * nc + 1];
+    const float g = gamma[c], b = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < P; i += 64) {
+        const float xh = (xp[i] - mean) * rstd;
+        float gr = dyp[i];
+        if (act != MGVAE_ACT_NONE) {
+            const float u = xh * g + b;
+            gr *= (u > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
+        }
+        s1 += gr; s2 += gr * xh;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        if (dgamma) atomicAdd(&dgamma[c], s2);
+        if (dbeta) atomicAdd(&dbeta[c], s1);
+    }
+    const float m1 = s1 / (float)P, m2 = s2 / (float)P, k = g * rstd;
+    for (int i = lane; i < P; i += 64) {
+        const float xh = (xp[i] - mean) * rstd;
+        float gr = dyp[i];
+        if (act != MGVAE_ACT_NONE) {
+            const float u = xh * g + b;
+            gr *= (u > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
+        }
+        dxp[i] = k * (gr - m1 - xh * m2);
+    }
+}
+
+// ------------------------------------------------------------------------ row mean
+__global__ __launch_bounds__(256) void rowmean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int rows, int L) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* xp = x + (size_t)r * L;
+    float s = 0.f;
+    for (int i = 0; i < L; ++i) s += xp[i];
+    out[r] = s / (float)L;
+}
+
+__global__ __launch_bounds__(256) void rowmean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
+                                                          long total, int L) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    dx[i] = dout[i / L] / (float)L;
+}
+
+// ------------------------------------------------------------------------ bias gradient
+// db[c] += sum over (n, p) of t[n, coff + c, p]; one workgroup per channel.
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, int N, int C, int P,
+                                                          int ctot, int coff, float* __restrict__ db) {
+    __shared__ float part[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    const long total = (long)N * P;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int n = (int)(i / P), pp = (int)(i - (long)n * P);
+        s += t[((size_t)n * ctot + coff + c) * P + pp];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&db[c], part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                       float* stats, int N, int C, int P, int y_ctot, int y_coff, float eps,
+                                       int act, float slope, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
+    if (y_coff < 0 || y_coff + C > y_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
+    const int NC = N * C;
+    hipLaunchKernelGGL(instance_norm_fwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
+                       beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
+                                       const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C,
+                                       int P, int dy_ctot, int dy_coff, int act, float slope, void* stream) {
+    if (!x || !gamma || !beta || !stats || !dy || !dx || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
+    if (dy_coff < 0 || dy_coff + C > dy_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
+    const int NC = N * C;
+    hipLaunchKernelGGL(instance_norm_bwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
+                       beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_rowmean_fwd(const float* x, float* out, int rows, int L, void* stream) {
+    if (!x || !out || rows <= 0 || L <= 0) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(rowmean_fwd_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), x, out, rows, L);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_rowmean_bwd(const float* dout, float* dx, int rows, int L, void* stream) {
+    if (!dout || !dx || rows <= 0 || L <= 0) return MGVAE_EINVAL;
+    const long total = (long)rows * L;
+    hipLaunchKernelGGL(rowmean_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), dout, dx, total, L);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_channel_sum_accum(const float* t, int N, int C, int P, int ctot, int coff, float* db,
+                                       void* stream) {
+    if (!t || !db || N <= 0 || C <= 0 || P <= 0 || coff < 0 || coff + C > ctot) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, as_stream(stream), t, N, C, P, ctot, coff, db);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}

@@ -1,0 +1,49 @@
+"""CBAM for the MI355X build (reference: graph/cbam.py).  The three classes keep the
+reference's names and parameters; ``CBAM`` runs channel + spatial attention AND the
+residual/activation that every caller applies right after it as one fused HIP op."""
+from torch import nn
+
+from hipops import functional as HF
+from graph.layers import Conv2d
+from graph.weights_initializer import weights_init
+
+
+class ChannelAttention(nn.Module):
+    """parameters of graph/cbam.py:7-29: conv1 [C/16,C,1,1], conv2 [C,C/16,1,1]"""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.conv1 = Conv2d(channel, channel // 16, 1, bias=False)
+        self.conv2 = Conv2d(channel // 16, channel, 1, bias=False)
+        self.apply(weights_init)
+
+    def forward(self, x):
+        raise NotImplementedError("ChannelAttention runs inside the fused CBAM HIP op; call CBAM(channel)(x)")
+
+
+class SpatialAttention(nn.Module):
+    """parameters of graph/cbam.py:32-52: conv [1,2,3,3]"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = Conv2d(2, 1, 3, padding=1, bias=False)
+        self.apply(weights_init)
+
+    def forward(self, x):
+        raise NotImplementedError("SpatialAttention runs inside the fused CBAM HIP op; call CBAM(channel)(x)")
+
+
+class CBAM(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        self.channel_attention = ChannelAttention(channel)
+        self.spatial_attention = SpatialAttention()
+        self.apply(weights_init)
+
+    def fused(self, u, mode, res=None, act=HF.ACT_NONE, slope=0.01, out=None):
+        """mode 1: act(u + cbam(u)); mode 2: act(res + cbam(u)); mode 0: cbam(u)"""
+        ca, sa = self.channel_attention, self.spatial_attention
+        return HF.cbam(u, ca.conv1.weight, ca.conv2.weight, sa.conv.weight, mode, res, act, slope, out)
+
+    def forward(self, x):
+        return self.fused(x, 0)

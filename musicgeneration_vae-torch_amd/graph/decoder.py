@@ -1,0 +1,148 @@
+"""Bar decoder on HIP kernels (reference: graph/decoder.py).
+
+Transposed convolutions run on the stride-phase data-gradient kernel (no zero taps);
+every ``torch.cat`` of the reference is a pre-allocated buffer whose channel slices the
+producers write directly."""
+import torch
+from torch import nn
+
+from hipops import functional as HF
+from graph.cbam import CBAM
+from graph.layers import Conv2d, ConvTranspose2d, Embedding, InstanceNorm2d, Linear
+from graph.weights_initializer import weights_init
+
+
+class _Stem(nn.Module):
+    """[B,2304,1,1] -> [B,1024,6,3] through two non-overlapping transposed convs"""
+    first, second = "time", "pitch"
+
+    def __init__(self):
+        super().__init__()
+        mk = {"time": lambda cin: ConvTranspose2d(cin, 1024, (6, 1), stride=(6, 1), bias=False),
+              "pitch": lambda cin: ConvTranspose2d(cin, 1024, (1, 3), stride=(1, 3), bias=False)}
+        setattr(self, self.first, mk[self.first](2304))
+        setattr(self, self.second, mk[self.second](1024))
+        self.bn = InstanceNorm2d(1024, eps=1e-5, momentum=0.01, affine=True)
+        self.cbam = CBAM(1024)
+        self.apply(weights_init)
+
+    def forward(self, x, out=None):
+        o = getattr(self, self.first)(x, act=HF.ACT_RELU)
+        o = getattr(self, self.second)(o)
+        return self.cbam.fused(self.bn(o), 1, act=HF.ACT_RELU, out=out)
+
+
+class TimePitchModule(_Stem):
+    """graph/decoder.py:8-36"""
+    first, second = "time", "pitch"
+
+
+class PitchTimeModule(_Stem):
+    """graph/decoder.py:39-66"""
+    first, second = "pitch", "time"
+
+
+class DeConvModule(nn.Module):
+    """graph/decoder.py:69-109: ConvT4x4 s2 || ConvT3x3 s2 (+bias) -> IN -> ReLU each; cat -> 1x1 -> IN -> +CBAM -> ReLU"""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.deConv1 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, bias=False)
+        self.deConv2 = ConvTranspose2d(in_channel, out_channel, 3, stride=2, padding=1, output_padding=1, bias=True)
+        self.conv = Conv2d(in_channel, out_channel, 1, stride=1, bias=False)
+        self.bn1 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.bn2 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.bn3 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.cbam = CBAM(out_channel)
+        self.out_channel = out_channel
+        self.apply(weights_init)
+
+    def forward(self, x, out=None):
+        co = self.out_channel
+        n, _, h, w = x.shape
+        cat = torch.empty((n, 2 * co, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+        a = self.bn1(self.deConv1(x), act=HF.ACT_RELU, out=cat[:, :co])
+        b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
+        u = self.bn3(self.conv(HF.join(cat, a, b)))
+        return self.cbam.fused(u, 1, act=HF.ACT_RELU, out=out)
+
+
+class DeConvPitchPadding(nn.Module):
+    """graph/decoder.py:112-154.  Literal about reference defect D5: ``bn2`` normalises BOTH
+    branches and ``bn1`` is never used (its parameters never receive a gradient)."""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.deConv1 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, output_padding=(0, 1), bias=True)
+        self.deConv2 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, output_padding=(0, 1), bias=True)
+        self.conv = Conv2d(in_channel, out_channel, 1, stride=1, bias=False)
+        self.bn1 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.bn2 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.bn3 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.cbam1 = CBAM(out_channel)
+        self.cbam2 = CBAM(out_channel)
+        self.out_channel = out_channel
+        self.apply(weights_init)
+
+    def forward(self, x, out=None):
+        co = self.out_channel
+        n, _, h, w = x.shape
+        cat = torch.empty((n, 2 * co, 2 * h, 2 * w + 1), device=x.device, dtype=torch.float32)
+        a = self.cbam1.fused(self.bn2(self.deConv1(x)), 1, act=HF.ACT_RELU, out=cat[:, :co])
+        b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
+        u = self.bn3(self.conv(HF.join(cat, a, b)))
+        return self.cbam2.fused(u, 1, act=HF.ACT_RELU, out=out)
+
+
+class Decoder(nn.Module):
+    """graph/decoder.py:157-222: (z, pre_z, phrase_feature, position) -> gen [B,1,96,60] in (0,1)"""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.bar_linear = Linear(1152 * 2, 1152)
+        self.phrase_linear = Linear(1152 * 2, 1152)
+        self.time = TimePitchModule()
+        self.pitch = PitchTimeModule()
+        self.fit1 = Conv2d(2048, 1024, 1, stride=1, bias=False)
+        self.bn = InstanceNorm2d(1024, eps=1e-5, momentum=0.01, affine=True)
+        self.fit2 = Conv2d(64, 1, 1, stride=1, bias=False)
+        blocks = []
+        for i in range(1, len(layers)):
+            blocks.append((DeConvPitchPadding if i < 3 else DeConvModule)(layers[i - 1], layers[i]))
+        self.layers = nn.ModuleList(blocks)
+        self.cbam = CBAM(1024)
+        self.position_embedding = Embedding(332, 1152)
+        nn.init.uniform_(self.position_embedding.weight, -1.0, 1.0)
+        self.dropout_p = 0.3
+        self._drop_masks = None     # tests inject two pre-scaled masks [B,1152] here
+        self.apply(weights_init)
+
+    def _drop(self, t, i):
+        m = self._drop_masks[i] if self._drop_masks is not None else None
+        return HF.dropout(t, self.dropout_p, self.training, mask=m)
+
+    def forward(self, z, pre_z, phrase_feature, position):
+        n, dev = z.shape[0], z.device
+        new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        # cat(phrase_feature, embedding(position)) -> Linear -> ReLU -> Dropout
+        pbuf = new(n, 2304)
+        pa = HF.copy_into(phrase_feature, pbuf[:, :1152])
+        pb = self.position_embedding(position, out=pbuf[:, 1152:])
+        pf = self._drop(self.phrase_linear(HF.join(pbuf, pa, pb), act=HF.ACT_RELU), 0)
+        # cat(z, pre_z) -> Linear -> ReLU -> Dropout
+        bbuf = new(n, 2304)
+        ba = HF.copy_into(z, bbuf[:, :1152])
+        bb = HF.copy_into(pre_z, bbuf[:, 1152:])
+        bf = self._drop(self.bar_linear(HF.join(bbuf, ba, bb), act=HF.ACT_RELU), 1)
+        xbuf = new(n, 2304)
+        xa = HF.copy_into(bf, xbuf[:, :1152])
+        xb = HF.copy_into(pf, xbuf[:, 1152:])
+        x = HF.join(xbuf, xa, xb).view(n, 2304, 1, 1)
+        cat = new(n, 2048, 6, 3)
+        pitch = self.pitch(x, out=cat[:, :1024])
+        time = self.time(x, out=cat[:, 1024:])
+        u = self.bn(self.fit1(HF.join(cat, pitch, time)))
+        o = self.cbam.fused(u, 1, act=HF.ACT_RELU)
+        for blk in self.layers:
+            o = blk(o)
+        return self.fit2(o, act=HF.ACT_SIGMOID)

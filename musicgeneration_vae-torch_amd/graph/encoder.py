@@ -1,0 +1,43 @@
+"""Bar encoder on HIP kernels (reference: graph/encoder.py:7-40)."""
+import torch
+from torch import nn
+
+from hipops import functional as HF
+from graph.encodingBlock import PitchTimeModule, PoolingModule, ResidualModule, TimePitchModule
+from graph.layers import Linear
+from graph.weights_initializer import weights_init
+
+
+class _ConvTrunk(nn.Module):
+    """two stems -> concat -> (Residual, Pooling) x 4 -> whole-map average -> Linear"""
+    pool_hw = (3, 2)
+    linear_bias = True
+
+    def __init__(self, layers):
+        super().__init__()
+        self.time_pitch = TimePitchModule()
+        self.pitch_time = PitchTimeModule()
+        blocks = []
+        for cin, cout in zip(layers[:-1], layers[1:]):
+            blocks += [ResidualModule(cin), PoolingModule(cin, cout)]
+        self.layers = nn.ModuleList(blocks)
+        self.linear = Linear(1024, 1152, bias=self.linear_bias)
+        self.apply(weights_init)
+
+    def forward(self, x):
+        n, _, h, w = x.shape
+        cat = torch.empty((n, 64, h // 2, w // 2), device=x.device, dtype=torch.float32)
+        pitch = self.pitch_time(x, out=cat[:, :32])
+        time = self.time_pitch(x, out=cat[:, 32:])
+        o = HF.join(cat, pitch, time)
+        for blk in self.layers:
+            o = blk(o)
+        if tuple(o.shape[2:]) != self.pool_hw:
+            raise RuntimeError("AvgPool2d%s expects a %s map, got %s" % (self.pool_hw, self.pool_hw, tuple(o.shape[2:])))
+        return self.linear(HF.global_avg_pool(o))
+
+
+class Encoder(_ConvTrunk):
+    """[B,1,96,60] -> z [B,1152]; AvgPool2d((3,2)) + Linear(1024,1152) with bias"""
+    pool_hw = (3, 2)
+    linear_bias = True

@@ -1,0 +1,72 @@
+"""Encoder building blocks on HIP kernels (reference: graph/encodingBlock.py).
+
+Each block is: implicit-GEMM conv(s) with the inner activation fused in the conv
+epilogue -> InstanceNorm -> fused CBAM + residual + activation.  ``out=`` lets a block
+write its result straight into a channel slice of its consumer's concat buffer."""
+from torch import nn
+
+from hipops import functional as HF
+from graph.cbam import CBAM
+from graph.layers import Conv2d, InstanceNorm2d
+from graph.weights_initializer import weights_init
+
+
+class _Stem(nn.Module):
+    """two thin 1-D convs; subclasses fix which axis goes first"""
+    first, second = "time", "pitch"
+
+    def __init__(self):
+        super().__init__()
+        convs = {"time": lambda cin: Conv2d(cin, 32, (4, 1), stride=(2, 1), padding=(1, 0), bias=False),
+                 "pitch": lambda cin: Conv2d(cin, 32, (1, 4), stride=(1, 2), padding=(0, 1), bias=False)}
+        setattr(self, self.first, convs[self.first](1))
+        setattr(self, self.second, convs[self.second](32))
+        self.bn = InstanceNorm2d(32, eps=1e-5, momentum=0.01, affine=True)
+        self.cbam = CBAM(32)
+        self.apply(weights_init)
+
+    def forward(self, x, out=None):
+        o = getattr(self, self.first)(x, act=HF.ACT_LEAKY, slope=0.01)
+        o = getattr(self, self.second)(o)
+        u = self.bn(o)
+        return self.cbam.fused(u, 1, act=HF.ACT_LEAKY, slope=0.01, out=out)
+
+
+class TimePitchModule(_Stem):
+    """graph/encodingBlock.py:8-36: conv(4,1)s(2,1) -> LeakyReLU -> conv(1,4)s(1,2) -> IN -> +CBAM -> LeakyReLU"""
+    first, second = "time", "pitch"
+
+
+class PitchTimeModule(_Stem):
+    """graph/encodingBlock.py:39-67: same with the axes swapped"""
+    first, second = "pitch", "time"
+
+
+class ResidualModule(nn.Module):
+    """graph/encodingBlock.py:70-100: relu(x + CBAM(IN(conv2(relu(conv1(x))))))"""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.conv1 = Conv2d(channel, channel, 3, stride=1, padding=1, bias=False)
+        self.conv2 = Conv2d(channel, channel, 3, stride=1, padding=1, bias=False)
+        self.bn = InstanceNorm2d(channel, eps=1e-5, momentum=0.01, affine=True)
+        self.cbam = CBAM(channel)
+        self.apply(weights_init)
+
+    def forward(self, x, out=None):
+        o = self.conv2(self.conv1(x, act=HF.ACT_RELU))
+        return self.cbam.fused(self.bn(o), 2, res=x, act=HF.ACT_RELU, out=out)
+
+
+class PoolingModule(nn.Module):
+    """graph/encodingBlock.py:103-126: relu(u + CBAM(u)), u = IN(conv3x3 s2 (x))"""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.conv = Conv2d(in_channel, out_channel, 3, stride=2, padding=1, bias=False)
+        self.bn = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        self.cbam = CBAM(out_channel)
+        self.apply(weights_init)
+
+    def forward(self, x, out=None):
+        return self.cbam.fused(self.bn(self.conv(x)), 1, act=HF.ACT_RELU, out=out)

@@ -1,0 +1,86 @@
+"""Parameter-holding leaf layers of the MI355X build.
+
+They keep torch's class NAMES (so the reference's ``weights_init`` name matching --
+graph/weights_initializer.py:5-23 -- behaves identically), parameter names, shapes and
+default initialisation, but their forward is a HIP launch through hipops.functional.
+"""
+import math
+
+import torch
+from torch import nn
+
+from hipops import functional as HF
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _default_init(weight, bias, fan_in):
+    nn.init.kaiming_uniform_(weight, a=math.sqrt(5))
+    if bias is not None:
+        bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+        nn.init.uniform_(bias, -bound, bound)
+
+
+class Conv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        _default_init(self.weight, self.bias, in_channels * self.kernel_size[0] * self.kernel_size[1])
+
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
+        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, slope, out)
+
+
+class ConvTranspose2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+        super().__init__()
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.output_padding = _pair(padding), _pair(output_padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        # torch derives fan_in of a transposed-conv weight from dim 1
+        _default_init(self.weight, self.bias, out_channels * self.kernel_size[0] * self.kernel_size[1])
+
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
+        return HF.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope, out)
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        _default_init(self.weight, self.bias, in_features)
+
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
+        return HF.linear(x, self.weight, self.bias, act, slope, out)
+
+
+class InstanceNorm2d(nn.Module):
+    """affine, no running statistics (the reference passes momentum=0.01, which is unused
+    without running stats)"""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.01, affine=True):
+        super().__init__()
+        if not affine:
+            raise ValueError("the hot path only uses affine InstanceNorm2d")
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
+        return HF.instance_norm(x, self.weight, self.bias, self.eps, act, slope, out)
+
+
+class Embedding(nn.Module):
+    def __init__(self, num_embeddings, embedding_dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_embeddings, embedding_dim))
+        nn.init.normal_(self.weight)
+
+    def forward(self, idx, out=None):
+        return HF.embedding(idx, self.weight, out)

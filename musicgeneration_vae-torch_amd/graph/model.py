@@ -1,0 +1,33 @@
+"""Generator wrapper (reference: graph/model.py:11-41).
+
+The reference's Refiner cannot run as committed (its ``layer2`` expects 1 input channel
+but receives 2: SURVEY defect D2), so calling ``Model.forward`` there raises.  This build
+keeps the signature and return structure; the refiner stage is an explicit, default-off
+option until its parity can be pinned."""
+from torch import nn
+
+from graph.decoder import Decoder
+from graph.encoder import Encoder
+from graph.phrase_encoder import PhraseModel
+from graph.weights_initializer import weights_init
+
+
+class Model(nn.Module):
+    def __init__(self, use_refiner=False):
+        super().__init__()
+        self.encoder = Encoder([64, 128, 256, 512, 1024])
+        self.decoder = Decoder([1024, 512, 256, 128, 64])
+        self.phrase_encoder = PhraseModel([64, 128, 256, 512, 1024])
+        if use_refiner:
+            raise NotImplementedError("Refiner: reference defect D2 (graph/refiner.py:19); scheduled after the hot path")
+        self.apply(weights_init)
+
+    def forward(self, note, pre_note, phrase, position, is_train=True):
+        phrase_feature = self.phrase_encoder(phrase)
+        pre_z = self.encoder(pre_note)
+        if is_train:
+            z = self.encoder(note)
+            gen = self.decoder(z, pre_z, phrase_feature, position)
+            return gen, z, pre_z, phrase_feature
+        # sampling: ``note`` is a latent [B,1152]
+        return self.decoder(note, pre_z, phrase_feature, position)

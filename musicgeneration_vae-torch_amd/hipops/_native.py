@@ -1,0 +1,85 @@
+"""ctypes binding of libmgvae_hip.so (the C ABI in include/mgvae.h).
+
+There is deliberately NO fallback: if the shared library is missing or a tensor is not
+on a ROCm device the call raises.  The library is built in-tree by
+``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmgvae_hip.so")
+
+c_int, c_float, c_size_t, c_void_p, c_u64 = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint64
+
+
+class ConvDesc(ctypes.Structure):
+    """MgvaeConvDesc (include/mgvae.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "Cx", "H", "W", "Cy", "OH", "OW", "KH", "KW", "SH", "SW", "PH", "PW",
+        "x_ctot", "x_coff", "y_ctot", "y_coff", "act")] + [("slope", ctypes.c_float)]
+
+
+class ProfRec(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("tile", ctypes.c_int32), ("launches", ctypes.c_int32),
+                ("ms", ctypes.c_double), ("flops", ctypes.c_double)]
+
+
+P = c_void_p
+# name -> (restype, argtypes); every symbol include/mgvae.h declares
+SIGNATURES = {
+    "mgvae_strerror": (ctypes.c_char_p, [c_int]),
+    "mgvae_device_info": (c_int, [ctypes.c_char_p, c_size_t, ctypes.POINTER(c_int)]),
+    "mgvae_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "mgvae_conv2d_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "mgvae_conv2d_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
+    "mgvae_channel_sum_accum": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "mgvae_instance_norm_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, P]),
+    "mgvae_instance_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "mgvae_cbam_save_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mgvae_cbam_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "mgvae_cbam_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mgvae_cbam_bwd": (c_int, [P] * 13 + [c_int] * 8 + [c_float, P]),
+    "mgvae_act_bwd": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
+    "mgvae_copy2d": (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
+    "mgvae_add_inplace": (c_int, [P, P, c_size_t, P]),
+    "mgvae_rowmean_fwd": (c_int, [P, P, c_int, c_int, P]),
+    "mgvae_rowmean_bwd": (c_int, [P, P, c_int, c_int, P]),
+    "mgvae_embedding_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_size_t, P]),
+    "mgvae_embedding_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_size_t, P]),
+    "mgvae_dropout_fwd": (c_int, [P, P, P, c_size_t, c_float, c_u64, c_u64, P]),
+    "mgvae_mul": (c_int, [P, P, P, c_size_t, P]),
+    "mgvae_randn": (c_int, [P, c_size_t, c_float, c_u64, c_u64, P]),
+    "mgvae_bce_partial_floats": (c_size_t, []),
+    "mgvae_bce_fwd": (c_int, [P, P, P, c_float, c_size_t, c_int, c_int, P, P, P]),
+    "mgvae_bce_bwd": (c_int, [P, P, P, c_float, c_size_t, c_int, P, P, P]),
+    "mgvae_reparam_kl_fwd": (c_int, [P, P, P, P, P, P, c_size_t, P]),
+    "mgvae_reparam_kl_bwd": (c_int, [P, P, P, P, P, P, P, c_size_t, P]),
+    "mgvae_adam_step": (c_int, [P, P, P, P, c_size_t, P, c_float, c_float, P]),
+    "mgvae_prof_enable": (c_int, [c_int]),
+    "mgvae_prof_collect": (c_int, [ctypes.POINTER(ProfRec), c_int]),
+    "mgvae_kernel_name": (ctypes.c_char_p, [c_int, c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmgvae_hip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmgvae_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "There is no CPU / eager fallback for the HIP hot path." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)     # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, lib().mgvae_strerror(rc).decode(), rc))

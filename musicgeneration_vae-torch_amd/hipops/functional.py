@@ -1,0 +1,527 @@
+"""torch.autograd bindings of the HIP kernels (C ABI: include/mgvae.h).
+
+PyTorch only supplies device memory, the current HIP stream and the autograd tape;
+every forward and backward below is one or more launches from libmgvae_hip.so.
+
+Conventions
+  * fp32, NCHW.  A tensor may be a *channel slice* ``buf[:, a:b]`` of a larger buffer
+    (that is how the reference's ``torch.cat(dim=1)`` is realised without a copy): ops
+    read the channel pitch from the strides.
+  * Weight-like gradients (conv / linear weights and biases, InstanceNorm affine, CBAM
+    weights, the embedding table) are ACCUMULATED straight into ``param.grad`` by the
+    backward kernels and ``None`` is returned to autograd for them -- the flat gradient
+    buffer (hipops.flat.FlatParams) is therefore written exactly once, by HIP code.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _s():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s: expected a ROCm device tensor; the MI355X hot path has no CPU fallback" % what)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s: expected float32, got %s" % (what, t.dtype))
+
+
+def _pitch(t):
+    """channel pitch (ctot) of an NCHW tensor that is dense or a channel slice; else None."""
+    n, c, h, w = t.shape
+    hw = h * w
+    st = t.stride()
+    if w > 1 and st[3] != 1:
+        return None
+    if h > 1 and st[2] != w:
+        return None
+    if c > 1 and st[1] != hw:
+        return None
+    if n > 1:
+        if st[0] % hw or st[0] // hw < c:
+            return None
+        return st[0] // hw
+    return c
+
+
+def _sliceable(t, what="tensor"):
+    """return (tensor, ctot); makes a dense copy only if the layout is not a channel slice"""
+    ct = _pitch(t)
+    if ct is None:
+        t = t.contiguous()
+        ct = t.shape[1]
+    return t, ct
+
+
+def grad_slot(p):
+    """the tensor the backward kernels accumulate into for parameter ``p``"""
+    g = p.grad
+    if g is None:
+        g = getattr(p, "_mg_grad", None)
+        if g is None:
+            g = torch.zeros_like(p)
+        else:
+            g.zero_()
+        p.grad = g
+    return g
+
+
+def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
+    return nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], x_ctot, 0, y_ctot, 0, act, slope)
+
+
+def _act_bwd(y, dy, act, slope):
+    """dx = dy * act'(y) -> dense tensor"""
+    y, yct = _sliceable(y)
+    dy, dct = _sliceable(dy)
+    n, c, h, w = y.shape
+    dx = torch.empty((n, c, h, w), device=y.device, dtype=torch.float32)
+    nat.check(nat.lib().mgvae_act_bwd(_p(y), _p(dy), _p(dx), n, c, h * w, yct, 0, dct, 0, c, 0, act, slope, _s()), "act_bwd")
+    return dx
+
+
+# =============================================================================== conv
+class _ConvFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward (reference: graph/encodingBlock.py:12-15,74-77,107-108;
+    graph/decoder.py:79,122,172,175) and, with H=W=1, nn.Linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, slope, out):
+        _need_cuda(x, "conv2d")
+        x, xct = _sliceable(x)
+        N, Cx, H, W = x.shape
+        Cy = w.shape[0]
+        KH, KW = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+        OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+        OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        y = out if out is not None else torch.empty((N, Cy, OH, OW), device=x.device, dtype=torch.float32)
+        yct = _pitch(y)
+        d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
+        nat.check(nat.lib().mgvae_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv2d_fwd")
+        ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.b = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, Cx, H, W, Cy, OH, OW, k, s, p, xct, act, slope = ctx.geom
+        L = nat.lib()
+        if act != ACT_NONE:
+            dy = _act_bwd(y, dy, act, slope)
+        dy, dct = _sliceable(dy)
+        d = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, xct, dct, ACT_NONE, 0.0)
+        if w.requires_grad:
+            nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_bwd_weight")
+        b = ctx.b
+        if b is not None and b.requires_grad:
+            nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Cy, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, Cx, H, W), device=dy.device, dtype=torch.float32)
+            d2 = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, Cx, dct, ACT_NONE, 0.0)
+            nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), _s()), "conv2d_bwd_data")
+        return dx, None, None, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=(1, 1), pad=(0, 0), act=ACT_NONE, slope=0.01, out=None):
+    return _ConvFn.apply(x, w, b, stride, pad, act, slope, out)
+
+
+def linear(x, w, b=None, act=ACT_NONE, slope=0.01, out=None):
+    """x [B, K] (dense or a column slice of a wider [B, ctot] buffer) -> [B, Cout]"""
+    B = x.shape[0]
+    x4 = x.unsqueeze(-1).unsqueeze(-1)
+    o4 = out.unsqueeze(-1).unsqueeze(-1) if out is not None else None
+    y = _ConvFn.apply(x4, w, b, (1, 1), (0, 0), act, slope, o4)
+    return y.view(B, -1) if out is None else y.squeeze(-1).squeeze(-1)
+
+
+class _ConvTFn(torch.autograd.Function):
+    """nn.ConvTranspose2d (graph/decoder.py:12-15,43-46,73-77,116-120): forward is the
+    stride-phase data-gradient kernel, d/dx is the forward-conv kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, opad, act, slope, out):
+        _need_cuda(x, "conv_transpose2d")
+        x, xct = _sliceable(x)
+        N, Ci, h, wd = x.shape
+        _, Co, KH, KW = w.shape
+        OH = (h - 1) * stride[0] - 2 * pad[0] + KH + opad[0]
+        OW = (wd - 1) * stride[1] - 2 * pad[1] + KW + opad[1]
+        y = out if out is not None else torch.empty((N, Co, OH, OW), device=x.device, dtype=torch.float32)
+        yct = _pitch(y)
+        # conv geometry: X = y (image side, Cx = Co), Y = x (feature side, Cy = Ci)
+        d = _desc(N, Co, OH, OW, Ci, h, wd, (KH, KW), stride, pad, yct, xct, act, slope)
+        nat.check(nat.lib().mgvae_conv2d_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv_transpose2d_fwd")
+        ctx.geom = (N, Co, OH, OW, Ci, h, wd, (KH, KW), stride, pad, xct, act, slope)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.b = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, Co, OH, OW, Ci, h, wd, k, s, p, xct, act, slope = ctx.geom
+        L = nat.lib()
+        if act != ACT_NONE:
+            dy = _act_bwd(y, dy, act, slope)
+        dy, dct = _sliceable(dy)
+        if w.requires_grad:
+            d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
+            nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_bwd_weight")
+        b = ctx.b
+        if b is not None and b.requires_grad:
+            nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Co, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, Ci, h, wd), device=dy.device, dtype=torch.float32)
+            d2 = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, Ci, ACT_NONE, 0.0)
+            nat.check(L.mgvae_conv2d_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), _s()), "convT_bwd_data")
+        return dx, None, None, None, None, None, None, None, None
+
+
+def conv_transpose2d(x, w, b=None, stride=(1, 1), pad=(0, 0), opad=(0, 0), act=ACT_NONE, slope=0.01, out=None):
+    return _ConvTFn.apply(x, w, b, stride, pad, opad, act, slope, out)
+
+
+# ====================================================================== instance norm
+class _InstNormFn(torch.autograd.Function):
+    """nn.InstanceNorm2d(affine) + fused (Leaky)ReLU (graph/encodingBlock.py:17,48,79,110;
+    graph/decoder.py:81-83,124-126,173)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, slope, out):
+        _need_cuda(x, "instance_norm")
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        y = out if out is not None else torch.empty_like(x)
+        yct = _pitch(y)
+        stats = torch.empty((N * C * 2,), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_instance_norm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), N, C, H * W, yct, 0,
+                                                    eps, act, slope, _s()), "instance_norm_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        act, slope = ctx.cfg
+        N, C, H, W = x.shape
+        dy, dct = _sliceable(dy)
+        dx = torch.empty_like(x)
+        dg = grad_slot(gamma) if gamma.requires_grad else None
+        db = grad_slot(beta) if beta.requires_grad else None
+        nat.check(nat.lib().mgvae_instance_norm_bwd(_p(x), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dx), _p(dg), _p(db),
+                                                    N, C, H * W, dct, 0, act, slope, _s()), "instance_norm_bwd")
+        return dx, None, None, None, None, None, None
+
+
+def instance_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.01, out=None):
+    return _InstNormFn.apply(x, gamma, beta, eps, act, slope, out)
+
+
+# ================================================================================ CBAM
+class _CbamFn(torch.autograd.Function):
+    """graph/cbam.py CBAM.forward fused with the residual/activation that follows it."""
+
+    @staticmethod
+    def forward(ctx, u, res, w1, w2, wsp, mode, act, slope, out):
+        _need_cuda(u, "cbam")
+        u = u.contiguous()
+        N, C, H, W = u.shape
+        if res is not None:
+            res = res.contiguous()
+        L = nat.lib()
+        y = out if out is not None else torch.empty_like(u)
+        yct = _pitch(y)
+        save = torch.empty((L.mgvae_cbam_save_floats(N, C, H, W),), device=u.device, dtype=torch.float32)
+        nat.check(L.mgvae_cbam_fwd(_p(u), _p(res), _p(w1), _p(w2), _p(wsp), _p(y), _p(save), N, C, H, W, yct, 0, mode, act,
+                                   slope, _s()), "cbam_fwd")
+        ctx.save_for_backward(u, y, w1, w2, wsp, save)
+        ctx.cfg = (mode, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, y, w1, w2, wsp, save = ctx.saved_tensors
+        mode, act, slope = ctx.cfg
+        N, C, H, W = u.shape
+        L = nat.lib()
+        yct = _pitch(y)
+        dy, dct = _sliceable(dy)
+        if dct != yct:    # the kernels address y and dy with one pitch
+            y, dy, yct = y.contiguous(), dy.contiguous(), C
+        du = torch.empty_like(u)
+        dres = torch.empty_like(u) if mode == 2 else None
+        scratch = torch.empty((L.mgvae_cbam_bwd_scratch_floats(N, C, H, W),), device=u.device, dtype=torch.float32)
+        dw1 = grad_slot(w1) if w1.requires_grad else None
+        dw2 = grad_slot(w2) if w2.requires_grad else None
+        dws = grad_slot(wsp) if wsp.requires_grad else None
+        nat.check(L.mgvae_cbam_bwd(_p(u), _p(y), _p(dy), _p(w1), _p(w2), _p(wsp), _p(save), _p(du), _p(dres), _p(dw1), _p(dw2),
+                                   _p(dws), _p(scratch), N, C, H, W, yct, 0, mode, act, slope, _s()), "cbam_bwd")
+        return du, dres, None, None, None, None, None, None, None
+
+
+def cbam(u, w1, w2, wsp, mode=0, res=None, act=ACT_NONE, slope=0.01, out=None):
+    return _CbamFn.apply(u, res, w1, w2, wsp, mode, act, slope, out)
+
+
+# ============================================================================ plumbing
+class _JoinFn(torch.autograd.Function):
+    """torch.cat(dim=1) with zero copies: the producers already wrote their channel
+    slices of ``buf``; backward hands each producer its slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.sizes = [t.shape[1] for t in parts]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, o = [], 0
+        for c in ctx.sizes:
+            outs.append(dy[:, o:o + c])
+            o += c
+        return (None,) + tuple(outs)
+
+
+def join(buf, *parts):
+    return _JoinFn.apply(buf, *parts)
+
+
+class _RowMeanFn(torch.autograd.Function):
+    """nn.AvgPool2d over the whole map (graph/encoder.py:20,35; graph/phrase_encoder.py:21,36)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "global_avg_pool")
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        out = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_rowmean_fwd(_p(x), _p(out), N * C, H * W, _s()), "rowmean_fwd")
+        ctx.shape = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, C, H, W = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty((N, C, H, W), device=dout.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_rowmean_bwd(_p(dout), _p(dx), N * C, H * W, _s()), "rowmean_bwd")
+        return dx
+
+
+def global_avg_pool(x):
+    return _RowMeanFn.apply(x)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding gather (graph/decoder.py:187,193), optionally into a column slice"""
+
+    @staticmethod
+    def forward(ctx, idx, table, out):
+        if not table.is_cuda:
+            raise RuntimeError("embedding: expected a ROCm device tensor; no CPU fallback")
+        idx = idx.to(device=table.device, dtype=torch.int64).contiguous()
+        B, (rows, D) = idx.numel(), table.shape
+        y = out if out is not None else torch.empty((B, D), device=table.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_embedding_fwd(_p(idx), _p(table), _p(y), B, D, rows, y.stride(0), _s()), "embedding_fwd")
+        ctx.save_for_backward(idx, table)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, table = ctx.saved_tensors
+        if table.requires_grad:
+            if dout.stride(1) != 1:
+                dout = dout.contiguous()
+            rows, D = table.shape
+            nat.check(nat.lib().mgvae_embedding_bwd(_p(idx), _p(dout), _p(grad_slot(table)), idx.numel(), D, rows,
+                                                    dout.stride(0), _s()), "embedding_bwd")
+        return None, None, None
+
+
+def embedding(idx, table, out=None):
+    return _EmbeddingFn.apply(idx, table, out)
+
+
+class _CopyIntoFn(torch.autograd.Function):
+    """dst[:, :] <- src for 2-D [B, D] tensors where dst is a column slice of a wider
+    buffer (a concat member that was produced elsewhere, e.g. a user-supplied latent)"""
+
+    @staticmethod
+    def forward(ctx, src, dst):
+        _need_cuda(src, "copy_into")
+        src = src.contiguous()
+        B, D = src.shape
+        nat.check(nat.lib().mgvae_copy2d(_p(dst), dst.stride(0), _p(src), D, D, B, _s()), "copy2d")
+        return dst.view(dst.shape)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, None
+
+
+def copy_into(src, dst_view):
+    return _CopyIntoFn.apply(src, dst_view)
+
+
+_rng_state = {"seed": 0x1234ABCD, "offset": 0}
+
+
+def manual_seed(seed, rank=0):
+    """seed the Philox streams used by dropout / prior noise (independent per rank)"""
+    _rng_state["seed"] = (int(seed) * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    _rng_state["offset"] = 0
+
+
+def _next_offset():
+    _rng_state["offset"] += 1
+    return _rng_state["offset"]
+
+
+class _DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) (graph/decoder.py:164,196,201) on the build's own Philox stream"""
+
+    @staticmethod
+    def forward(ctx, x, p, mask_in):
+        _need_cuda(x, "dropout")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        if mask_in is None:
+            mask = torch.empty_like(x)
+            nat.check(nat.lib().mgvae_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), p, _rng_state["seed"], _next_offset(),
+                                                  _s()), "dropout_fwd")
+        else:
+            mask = mask_in.contiguous()
+            nat.check(nat.lib().mgvae_mul(_p(x), _p(mask), _p(y), x.numel(), _s()), "dropout_mask")
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        nat.check(nat.lib().mgvae_mul(_p(dy), _p(mask), _p(dx), dy.numel(), _s()), "dropout_bwd")
+        return dx, None, None
+
+
+def dropout(x, p=0.3, training=True, mask=None):
+    if mask is None and (not training or p == 0.0):
+        return x
+    return _DropoutFn.apply(x, p, mask)
+
+
+def randn(shape, sigma=1.0, device="cuda"):
+    """Gaussian prior noise N(0, sigma^2) generated on the device (agent/barGen2.py:243,250)"""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    nat.check(nat.lib().mgvae_randn(_p(out), out.numel(), sigma, _rng_state["seed"], _next_offset(), _s()), "randn")
+    return out
+
+
+# ============================================================================== losses
+_prior_cache = {}
+
+
+def _prior(device, prior_np):
+    key = (str(device), id(prior_np))
+    t = _prior_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(np.asarray(prior_np, dtype=np.float32)).to(device)
+        _prior_cache[key] = t
+    return t
+
+
+class _BceFn(torch.autograd.Function):
+    """nn.BCELoss (mean) as used by graph/loss/bar_loss.py Loss / DLoss"""
+
+    @staticmethod
+    def forward(ctx, x, targets, prior, tconst, mode, count_term):
+        _need_cuda(x, "bce")
+        x = x.contiguous()
+        if targets is not None:
+            targets = targets.contiguous()
+        L = nat.lib()
+        partial = torch.empty((L.mgvae_bce_partial_floats(),), device=x.device, dtype=torch.float32)
+        out = torch.empty((1,), device=x.device, dtype=torch.float32)
+        nat.check(L.mgvae_bce_fwd(_p(x), _p(targets), _p(prior), tconst, x.numel(), mode, count_term, _p(partial), _p(out),
+                                  _s()), "bce_fwd")
+        ctx.save_for_backward(x, targets, prior)
+        ctx.cfg = (tconst, mode)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, targets, prior = ctx.saved_tensors
+        tconst, mode = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        nat.check(nat.lib().mgvae_bce_bwd(_p(x), _p(targets), _p(prior), tconst, x.numel(), mode, _p(g), _p(dx), _s()), "bce_bwd")
+        return dx, None, None, None, None, None
+
+
+def bce(x, targets):
+    """F.binary_cross_entropy(x, targets) -- mean reduction, log clamp at -100"""
+    return _BceFn.apply(x, targets, None, 0.0, 0, 0)
+
+
+def bce_const(x, value):
+    """BCE against an all-``value`` target (DLoss with valid/fake targets)"""
+    return _BceFn.apply(x, None, None, float(value), 2, 0)
+
+
+def bar_recon_loss(gen, labels, prior_scaled, is_pretraining):
+    """graph/loss/bar_loss.py:23-33 in one pass: BCE (plain or label-smoothed) + 0.005 * #missed notes"""
+    if is_pretraining:
+        return _BceFn.apply(gen, labels, None, 0.0, 0, 1)
+    return _BceFn.apply(gen, labels, _prior(gen.device, prior_scaled), 0.0, 1, 1)
+
+
+class _ReparamKlFn(torch.autograd.Function):
+    """old/graphs/models/bar_v1/encoder.py:60-63 + old/graphs/losses/loss.py:14-17"""
+
+    @staticmethod
+    def forward(ctx, mean, logvar, eps):
+        _need_cuda(mean, "reparam_kl")
+        mean, logvar, eps = mean.contiguous(), logvar.contiguous(), eps.contiguous()
+        L = nat.lib()
+        z = torch.empty_like(mean)
+        partial = torch.empty((L.mgvae_bce_partial_floats(),), device=mean.device, dtype=torch.float32)
+        kl = torch.empty((1,), device=mean.device, dtype=torch.float32)
+        nat.check(L.mgvae_reparam_kl_fwd(_p(mean), _p(logvar), _p(eps), _p(z), _p(partial), _p(kl), mean.numel(), _s()),
+                  "reparam_kl_fwd")
+        ctx.save_for_backward(mean, logvar, eps)
+        return z, kl.view(())
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        mean, logvar, eps = ctx.saved_tensors
+        dz = dz.contiguous() if dz is not None else torch.zeros_like(mean)
+        dkl = dkl.contiguous() if dkl is not None else torch.zeros((), device=mean.device)
+        dm, dlv = torch.empty_like(mean), torch.empty_like(mean)
+        nat.check(nat.lib().mgvae_reparam_kl_bwd(_p(mean), _p(logvar), _p(eps), _p(dz), _p(dkl), _p(dm), _p(dlv), mean.numel(),
+                                                 _s()), "reparam_kl_bwd")
+        return dm, dlv, None
+
+
+def reparam_kl(mean, logvar, eps=None):
+    """z = mean + eps * exp(0.5 logvar); kl = -0.5 sum(1 + logvar - mean^2 - exp(logvar))"""
+    if eps is None:
+        eps = randn(tuple(mean.shape), 1.0, mean.device)
+    return _ReparamKlFn.apply(mean, logvar, eps)

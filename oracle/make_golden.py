@@ -98,6 +98,9 @@ def main():
         print("mode", mode)
         fx = {}
         sds = {k: W.make_state_dict(man, seed=0, mode=mode) for k, (_, man) in manifests.items()}
+        # canonical generator weights are keyed by their full generator names
+        sds["encoder"], sds["decoder"], sds["phrase_encoder"] = W.split_generator(
+            W.make_state_dict(W.manifest_generator(), seed=0, mode=mode))
         for k, (mod, _) in manifests.items():
             mod.load_state_dict(sds[k])
             mod.eval()

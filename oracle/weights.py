@@ -203,6 +203,14 @@ def make_state_dict(manifest, seed=0, mode="d4", dtype=torch.float32):
     return sd
 
 
+def split_generator(gsd):
+    """generator state_dict -> (encoder, decoder, phrase_model) sub-dicts with the prefix stripped"""
+    out = []
+    for pref in ("encoder.", "decoder.", "phrase_encoder."):
+        out.append({k[len(pref):]: v for k, v in gsd.items() if k.startswith(pref)})
+    return tuple(out)
+
+
 def make_inputs(batch, seed=1234, p_on=0.05):
     """Synthetic piano-roll batch: Bernoulli(p_on) rolls, uniform positions."""
     rng = np.random.default_rng(seed)
