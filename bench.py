@@ -1,0 +1,218 @@
+"""Headline benchmark: bars/sec of one bar-VAE training step (forward + backward + Adam, incl.
+the data-parallel gradient all-reduce) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the barGen2 pre-training generator step
+(reference: agent/barGen2.py:267-292) -- PhraseEncoder + 2 x Encoder + Decoder forward, three
+frozen z-discriminator forwards, Loss(is_pretraining=True), backward, Adam(lr 0.002) -- at
+batch 64 per GPU, fp32, synthetic Bernoulli(0.05) piano rolls, weights_init (D4) weights.
+The Refiner is excluded (it raises in the reference: defect D2).  Weak scaling: the per-GPU
+batch stays 64 as N grows.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel family (implicit-GEMM convs on the fp32 MFMA pipe):
+                  algorithmic FLOPs / HIP-event time measured live, per kernel variant,
+                  against the 157.3 TFLOP/s dense fp32 matrix peak of MI355X;
+  cpu_baseline -- the CPU oracle (a restatement pinned bit-for-bit to the reference import)
+                  running the same step at batch 4 on this host's cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "musicgeneration_vae-torch_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_BAR_STEP = 29.5e9               # 3 x 9.83 GFLOP forward
+
+
+def synth_batch(batch, seed, device):
+    rng = np.random.default_rng(seed)
+    note = (rng.random((batch, 1, 96, 60)) < 0.05).astype(np.float32)
+    pre = (rng.random((batch, 1, 96, 60)) < 0.05).astype(np.float32)
+    phrase = (rng.random((batch, 1, 384, 60)) < 0.05).astype(np.float32)
+    pos = rng.integers(0, 332, size=(batch,), dtype=np.int64)
+    return tuple(torch.from_numpy(a).to(device) for a in (note, pre, phrase, pos))
+
+
+def host_cores():
+    """cores this process may really use (affinity / cgroup quota), capped at 16: the GPU
+    box gives one GPU's job a 16-core share, and oversubscribing torch threads stalls it"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
+def cpu_baseline(batch=4, steps=2):
+    """the oracle's training step (torch CPU fp32, autograd + Adam) on this host's cores"""
+    from oracle import restate as R
+    from oracle import weights as W
+    torch.set_num_threads(host_cores())
+    gsd = {k: v.requires_grad_(True) for k, v in W.make_state_dict(W.manifest_generator(), 0, "d4").items()}
+    zsd = W.make_state_dict(W.manifest_z_discriminator(), 0, "d4")
+    names = list(gsd)
+    params = [gsd[n] for n in names]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    note, pre, phrase, pos = W.make_inputs(batch, seed=1234)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        loss, _ = R.pretrain_step_loss(gsd, zsd, zsd, note, pre, phrase, pos, True)
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
+        R.adam_step(params, grads, m, v, it + 1)
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    return {"value": batch / dt, "unit": "bars/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed steps (after 1 warm-up) of the same pre-training step at batch %d, fp32, torch %s CPU"
+                      % (steps, batch, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="bars per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from hipops import _native as nat
+    from hipops import functional as HF
+    from hipops.train import PretrainStep
+    from graph.model import Model
+    from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
+    from graph.loss.bar_loss import Loss, DLoss
+
+    arch = ctypes.create_string_buffer(64)
+    cus = ctypes.c_int(0)
+    nat.check(nat.lib().mgvae_device_info(arch, 64, ctypes.byref(cus)), "device_info")
+
+    torch.manual_seed(0)
+    gen, zb, zp = Model().to(dev).train(), BarZDiscriminator().to(dev), PhraseZDiscriminator().to(dev)
+    for d in (zb, zp):
+        for p in d.parameters():
+            p.requires_grad = False
+    HF.manual_seed(1234, rank)
+    step = PretrainStep(gen, zb, zp, Loss().to(dev), DLoss(), lr=0.002)
+    batch = synth_batch(args.batch, 1234 + rank, dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("model built on %s (%d CUs); warm-up" % (arch.value.decode(), cus.value))
+    for i in range(args.warmup):
+        step(*batch)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    sync_all()
+    log("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step(*batch)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    log("timed region: %.1f ms/step" % (1e3 * dt / args.steps))
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        # one extra (untimed) step with every conv launch bracketed by hipEvents on its stream
+        L = nat.lib()
+        L.mgvae_prof_enable(1)
+        step(*batch)
+        torch.cuda.synchronize()
+        recs = (nat.ProfRec * 16)()
+        n = L.mgvae_prof_collect(recs, 16)
+        L.mgvae_prof_enable(0)
+        fam = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,
+                "avg_us": 1e3 * r.ms / r.launches, "tflops": r.flops / (r.ms * 1e-3) / 1e12} for r in recs[:n]]
+        fam.sort(key=lambda f: -f["ms"])
+        tot_ms = sum(f["ms"] for f in fam)
+        tot_fl = sum(r.flops for r in recs[:n])
+        top = fam[0]
+        roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": top["tflops"] / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_us": top["avg_us"], "launches_per_step": top["launches"],
+                "all_conv_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                                     "share_of_step_time": tot_ms / (1e3 * dt / args.steps)},
+                "variants": fam}
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline on %d cores" % host_cores())
+        base = cpu_baseline()
+        log("cpu baseline done")
+
+    if rank == 0:
+        value = args.batch * world * args.steps / dt
+        out = {
+            "metric": "bars/sec VAE training step (fwd+bwd+opt) at 1/2/4/8 MI355X", "value": value, "unit": "bars/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "barGen2 pre-training generator step: PhraseEncoder + 2x Encoder + Decoder fwd, 3 frozen "
+                                   "z-discriminators, Loss, bwd, Adam; Refiner excluded (reference defect D2)",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "weights": "weights_init (D4) random", "device": arch.value.decode(), "cus": cus.value},
+            "step_tflops": value * FLOP_PER_BAR_STEP / 1e12, "loss": final_loss,
+            "roofline": roof, "cpu_baseline": base,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
