@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="bars per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-detail", default="", help="write one CSV row per conv launch of the profiled step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,12 +172,15 @@ def main():
     if not args.no_roofline and rank == 0:
         # one extra (untimed) step with every conv launch bracketed by hipEvents on its stream
         L = nat.lib()
+        if args.prof_detail:
+            L.mgvae_prof_detail(args.prof_detail.encode())
         L.mgvae_prof_enable(1)
         step(*batch)
         torch.cuda.synchronize()
         recs = (nat.ProfRec * 16)()
         n = L.mgvae_prof_collect(recs, 16)
         L.mgvae_prof_enable(0)
+        L.mgvae_prof_detail(b"")
         fam = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,
                 "avg_us": 1e3 * r.ms / r.launches, "tflops": r.flops / (r.ms * 1e-3) / 1e12} for r in recs[:n]]
         fam.sort(key=lambda f: -f["ms"])

@@ -71,6 +71,18 @@ int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w
 /* dWt += corr(X, Y): weight gradient of either layer type (split-K, fp32 atomics)    */
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                             void* stream);
+/* Faster path of the two calls above: direct (halo-tile) convolution with pre-packed weights.
+ * mode 0 packs for mgvae_conv2d_fwd_packed, mode 1 for mgvae_conv2d_bwd_data_packed (one
+ * packed block per stride phase).  mgvae_conv_pack_floats returns the workspace size in floats
+ * (0 = geometry not supported by the direct kernel: use the unpacked entry points).  Packing is
+ * ~2 HBM passes over the weight and is redone whenever the weight changed; descriptors must use
+ * x_coff = y_coff = 0 (pass pointers to the first channel of a slice).                         */
+size_t mgvae_conv_pack_floats(const MgvaeConvDesc* d, int mode);
+int mgvae_conv_pack(const MgvaeConvDesc* d, int mode, const float* w, float* packed, void* stream);
+int mgvae_conv2d_fwd_packed(const MgvaeConvDesc* d, const float* x, const float* packed, const float* bias,
+                            float* y, void* stream);
+int mgvae_conv2d_bwd_data_packed(const MgvaeConvDesc* d, const float* y, const float* packed, const float* bias,
+                                 float* x, void* stream);
 /* db[c] += sum_{n,h,w} t[n, coff+c, h, w]   (bias gradient of Conv/ConvT/Linear)     */
 int mgvae_channel_sum_accum(const float* t, int N, int C, int P, int ctot, int coff, float* db,
                             void* stream);
@@ -167,10 +179,15 @@ int mgvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, cons
  * When enabled, every mgvae_conv2d_* launch is bracketed by hipEvents on its stream and
  * its algorithmic FLOPs are recorded.  mgvae_prof_collect synchronises the events and
  * returns per-kernel-variant totals: up to `cap` records of
- * {kind (0 fwd,1 bwd_data,2 bwd_weight), tile id, launches, total ms, total flops}.    */
+ * {kind (0 fwd,1 bwd_data,2 bwd_weight igemm; 3 fwd,4 bwd_data direct), tile id, launches, total ms, total flops}.    */
 typedef struct MgvaeProfRec { int32_t kind, tile, launches; double ms, flops; } MgvaeProfRec;
 int mgvae_prof_enable(int on);
 int mgvae_prof_collect(MgvaeProfRec* out, int cap);
+/* optional: write one CSV row per profiled launch (geometry, grid, us, TFLOP/s) at collect time */
+int mgvae_prof_detail(const char* path);
+/* bracket any launch with profiler events (used by the direct-conv path; kind 3/4) */
+int mgvae_prof_record_begin(int kind, int tile, double flops, void* stream, void** token);
+int mgvae_prof_record_end(void* token, void* stream);
 const char* mgvae_kernel_name(int kind, int tile);
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@
 // writes and the MFMA fragment reads (ds_read_b32, lanes 0-31 / 32-63) are
 // conflict-free.
 #include "mgvae_common.h"
+#include <cstdio>
 #include <mutex>
 #include <vector>
 
@@ -32,6 +33,7 @@ struct IgemmP {
     int act;
     float slope;
     int kchunk;         // bwd_weight: pixels per split
+    int ksplit;         // fwd / bwd_data: K splits (blockIdx.z = phase * ksplit + split); >1 => atomic epilogue
 };
 
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
@@ -105,14 +107,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     int Itot, Jtot, kbeg, kend, T;
     // bwd_data phase constants
     int rh = 0, rw = 0, Wb = 1, Pp = 1;
+    int Ktot = 0, split = 0;
     if constexpr (MODE == MODE_FWD) {
-        Itot = p.Cy; Jtot = p.N * P; T = p.KH * p.KW; kbeg = 0; kend = p.Cx * T;
+        Itot = p.Cy; Jtot = p.N * P; T = p.KH * p.KW; Ktot = p.Cx * T;
+        split = blockIdx.z;
+        const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+        kbeg = split * kc; kend = min(Ktot, kbeg + kc);
         if (tid < T) {
             const int kh = tid / p.KW, kw = tid - kh * p.KW;
             tap_dh[tid] = kh; tap_dw[tid] = kw; tap_off[tid] = kh * p.W + kw;
         }
     } else if constexpr (MODE == MODE_BWD_DATA) {
-        const int ph = blockIdx.z;
+        const int ph = blockIdx.z / p.ksplit;
+        split = blockIdx.z - ph * p.ksplit;
         rh = ph / p.SW; rw = ph - rh * p.SW;
         const int kh0 = (rh + p.PH) % p.SH, kw0 = (rw + p.PW) % p.SW;
         const int nkh = kh0 < p.KH ? (p.KH - kh0 + p.SH - 1) / p.SH : 0;
@@ -121,7 +128,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         const int Ha = rh < p.H ? (p.H - rh + p.SH - 1) / p.SH : 0;
         Wb = rw < p.W ? (p.W - rw + p.SW - 1) / p.SW : 0;
         Pp = Ha * Wb;
-        Itot = p.Cx; Jtot = p.N * Pp; T = nkh * nkw; kbeg = 0; kend = p.Cy * T;
+        Itot = p.Cx; Jtot = p.N * Pp; T = nkh * nkw; Ktot = p.Cy * T;
+        {
+            const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+            kbeg = split * kc; kend = min(Ktot, kbeg + kc);
+            if (split > 0 && kbeg >= Ktot) return;   // nothing left for this split (split 0 still writes bias)
+        }
         if (Jtot == 0 || j0 >= Jtot) return;   // uniform across the workgroup
         if (tid < T) {
             const int jh = tid / nkw, jw = tid - jh * nkw;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             tap_off[tid] = (qh - jh) * p.OW + (qw - jw);
             tap_w[tid] = (kh0 + p.SH * jh) * p.KW + kw0 + p.SW * jw;
         }
-        if (T == 0) T = 1;   // kend == 0: loop never runs, keep divisions defined
+        if (T == 0) { T = 1; kbeg = 0; kend = 0; }   // no taps: loop never runs, keep divisions defined
     } else {
         Itot = p.Cy; Jtot = p.Cx * p.KH * p.KW; T = 1;
         kbeg = blockIdx.z * p.kchunk;
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         b_r0 = oh * p.SH - p.PH; b_c0 = ow * p.SW - p.PW;
         b_pix = (n * p.x_ctot + p.x_coff) * HW + b_r0 * p.W + b_c0;
         b_RH = p.H; b_RW = p.W; b_cstride = HW;
-        bk.init(jkr0, T);
+        bk.init(kbeg + jkr0, T);
     } else if constexpr (MODE == MODE_BWD_DATA) {
         const int j = j0 + jc * 64 + lane;
         bj_valid = j < Jtot;
@@ -176,10 +188,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         b_r0 = a; b_c0 = b;
         b_pix = (n * p.y_ctot + p.y_coff) * P + a * p.OW + b;
         b_RH = p.OH; b_RW = p.OW; b_cstride = P;
-        bk.init(jkr0, T);
+        bk.init(kbeg + jkr0, T);
         a_i = i0 + ic * 64 + lane;
         ai_valid = a_i < Itot;
-        ak.init(ikr0, T);
+        ak.init(kbeg + ikr0, T);
     } else {
         const int kp = kbeg + kl;
         w_n = kp / P; w_p = kp - w_n * P;
@@ -203,12 +215,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     auto load_tile = [&](int k0) {
         // ------------------------------ A operand ------------------------------
         if constexpr (MODE == MODE_FWD) {
-            const int K = kend;
             const int gk = k0 + kl;
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const int gi = i0 + rr + 16 * r;
-                ra[r] = (gi < Itot && gk < K) ? p.Wt[(size_t)gi * K + gk] : 0.f;
+                ra[r] = (gi < Itot && gk < kend) ? p.Wt[(size_t)gi * Ktot + gk] : 0.f;
             }
         } else if constexpr (MODE == MODE_BWD_DATA) {
             const int KK = p.KH * p.KW;
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
-    const int nt = (kend - kbeg + BK - 1) / BK;
+    const int nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     if (nt > 0) {
         load_tile(kbeg);
         store_tile(0);
@@ -337,8 +348,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
                     const int gi = i0 + wi * 32 * TI + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (gi < Itot) {
                         float v = acc[ti][tj][r];
-                        if (p.bias) v += p.bias[gi];
-                        p.out[obase + gi * cstride] = apply_act(v, p.act, p.slope);
+                        if (p.ksplit > 1) {       // split-K: caller zeroed the output, activation runs afterwards
+                            if (p.bias && split == 0) v += p.bias[gi];
+                            atomicAdd(&p.out[obase + gi * cstride], v);
+                        } else {
+                            if (p.bias) v += p.bias[gi];
+                            p.out[obase + gi * cstride] = apply_act(v, p.act, p.slope);
+                        }
                     }
                 }
             }
@@ -346,11 +362,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     }
 }
 
+// zero / activate a channel-sliced tensor [N, C, P] living in a buffer with ctot channels
+__global__ __launch_bounds__(256) void slice_zero_kernel(float* __restrict__ t, long row, long pitch, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / row, r = i - n * row;
+        t[n * pitch + r] = 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void slice_act_kernel(float* __restrict__ t, long row, long pitch, long total, int act,
+                                                        float slope) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / row, r = i - n * row;
+        t[n * pitch + r] = apply_act(t[n * pitch + r], act, slope);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
-static int g_cus = 256;
+int g_mgvae_cus = 256;
+#define g_cus g_mgvae_cus
 static bool g_prof = false;
-struct ProfEntry { int kind, tile; double flops; hipEvent_t e0, e1; };
+struct ProfEntry { int kind, tile; double flops; hipEvent_t e0, e1; IgemmP p; unsigned gx, gy, gz; };
 static std::vector<ProfEntry> g_prof_entries;
 static std::mutex g_prof_mu;
 
@@ -373,18 +405,35 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.N = d->N; p.Cx = d->Cx; p.H = d->H; p.W = d->W; p.Cy = d->Cy; p.OH = d->OH; p.OW = d->OW;
     p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
-    p.act = d->act; p.slope = d->slope; p.kchunk = 0;
+    p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1;
     return p;
 }
 
-// tile ids: 0 = 128x128, 1 = 64(i)x128(j), 2 = 128(i)x64(j), 3 = 64x64
-static int pick_tile(long Itot, long Jtot, int Z) {
+// tile ids: 0 = 128x128, 1 = 64(i)x128(j), 2 = 128(i)x64(j), 3 = 64x64.
+// Under-filled launches first split K (keeps the efficient big tiles), then shrink the tile.
+static int pick_tile(long Itot, long Jtot, int Z, long Kmin, int* ksplit) {
     int ti = Itot > 64 ? 2 : 1, tj = Jtot > 64 ? 2 : 1;
     auto wgs = [&](int a, int b) { return (long)cdiv(Itot, 64 * a) * cdiv(Jtot, 64 * b) * Z; };
-    const long want = (long)g_cus * 3 / 2;
-    if (wgs(ti, tj) < want && tj == 2) tj = 1;
-    if (wgs(ti, tj) < want && ti == 2) ti = 1;
+    const long want = (long)g_cus * 2;
+    const long maxsplit = Kmin / (BK * 8) > 1 ? Kmin / (BK * 8) : 1;
+    if (wgs(ti, tj) * maxsplit < want && tj == 2) tj = 1;
+    if (wgs(ti, tj) * maxsplit < want && ti == 2) ti = 1;
+    long sp = cdiv(want, wgs(ti, tj));
+    if (sp > maxsplit) sp = maxsplit;
+    if (sp > 32) sp = 32;
+    *ksplit = sp < 1 ? 1 : (int)sp;
     return (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
+}
+
+static void zero_slice(float* t, int N, int C, long P, int ctot, hipStream_t s) {
+    const long row = (long)C * P, total = row * N;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(slice_zero_kernel, dim3(blocks), dim3(256), 0, s, t, row, (long)ctot * P, total);
+}
+static void act_slice(float* t, int N, int C, long P, int ctot, int act, float slope, hipStream_t s) {
+    const long row = (long)C * P, total = row * N;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(slice_act_kernel, dim3(blocks), dim3(256), 0, s, t, row, (long)ctot * P, total, act, slope);
 }
 
 template <int MODE>
@@ -402,7 +451,7 @@ static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
 template <int MODE>
 static int run(int tile, dim3 grid, const IgemmP& p, hipStream_t s, double flops) {
     if (!g_prof) return launch<MODE>(tile, grid, p, s);
-    ProfEntry pe{MODE, tile, flops, nullptr, nullptr};
+    ProfEntry pe{MODE, tile, flops, nullptr, nullptr, p, grid.x, grid.y, grid.z};
     if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess) return MGVAE_ELAUNCH;
     hipEventRecord(pe.e0, s);
     int rc = launch<MODE>(tile, grid, p, s);
@@ -410,6 +459,31 @@ static int run(int tile, dim3 grid, const IgemmP& p, hipStream_t s, double flops
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_entries.push_back(pe);
     return rc;
+}
+
+thread_local int g_prof_note[16] = {0};
+// profiler hooks shared with conv_direct.hip (kinds 3 = direct fwd, 4 = direct bwd_data)
+extern "C" int mgvae_prof_record_begin(int kind, int tile, double flops, void* stream, void** token) {
+    *token = nullptr;
+    if (!g_prof) return MGVAE_OK;
+    ProfEntry* pe = new ProfEntry{kind, tile, flops, nullptr, nullptr, IgemmP{}, 0, 0, 0};
+    IgemmP& q = pe->p;
+    q.N = g_prof_note[0]; q.Cx = g_prof_note[1]; q.H = g_prof_note[2]; q.W = g_prof_note[3]; q.Cy = g_prof_note[4];
+    q.OH = g_prof_note[5]; q.OW = g_prof_note[6]; q.KH = g_prof_note[7]; q.KW = g_prof_note[8]; q.SH = g_prof_note[9];
+    q.SW = g_prof_note[10]; pe->gx = g_prof_note[11]; pe->gy = g_prof_note[12]; pe->gz = g_prof_note[13];
+    if (hipEventCreate(&pe->e0) != hipSuccess || hipEventCreate(&pe->e1) != hipSuccess) { delete pe; return MGVAE_ELAUNCH; }
+    hipEventRecord(pe->e0, as_stream(stream));
+    *token = pe;
+    return MGVAE_OK;
+}
+extern "C" int mgvae_prof_record_end(void* token, void* stream) {
+    if (!token) return MGVAE_OK;
+    ProfEntry* pe = static_cast<ProfEntry*>(token);
+    hipEventRecord(pe->e1, as_stream(stream));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_entries.push_back(*pe);
+    delete pe;
+    return MGVAE_OK;
 }
 
 extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
@@ -420,10 +494,16 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     IgemmP p = make_params(d);
     p.X = x; p.Wt = w; p.bias = bias; p.out = y; p.Y = nullptr;
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
-    const int tile = pick_tile(I, J, 1);
+    int ksplit = 1;
+    const int tile = pick_tile(I, J, 1, (long)d->Cx * d->KH * d->KW, &ksplit);
     const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
-    dim3 grid(cdiv(J, jt), cdiv(I, it), 1);
-    return run<MODE_FWD>(tile, grid, p, as_stream(stream), 2.0 * I * J * d->Cx * d->KH * d->KW);
+    p.ksplit = ksplit;
+    if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(y + (size_t)d->y_coff * d->OH * d->OW, d->N, d->Cy, (long)d->OH * d->OW, d->y_ctot, as_stream(stream)); }
+    dim3 grid(cdiv(J, jt), cdiv(I, it), ksplit);
+    rc = run<MODE_FWD>(tile, grid, p, as_stream(stream), 2.0 * I * J * d->Cx * d->KH * d->KW);
+    if (rc == MGVAE_OK && ksplit > 1 && d->act != MGVAE_ACT_NONE)
+        act_slice(y + (size_t)d->y_coff * d->OH * d->OW, d->N, d->Cy, (long)d->OH * d->OW, d->y_ctot, d->act, d->slope, as_stream(stream));
+    return rc;
 }
 
 extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
@@ -436,12 +516,20 @@ extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, con
     const int Z = d->SH * d->SW;
     const long I = d->Cx;
     const long J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
-    const int tile = pick_tile(I, J, Z);
+    // smallest per-phase K: Cy * (fewest taps a phase has, at least 1)
+    const long tmin = (long)(d->KH / d->SH > 0 ? d->KH / d->SH : 1) * (d->KW / d->SW > 0 ? d->KW / d->SW : 1);
+    int ksplit = 1;
+    const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit);
     const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
-    dim3 grid(cdiv(J, jt), cdiv(I, it), Z);
+    p.ksplit = ksplit;
+    if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(x + (size_t)d->x_coff * d->H * d->W, d->N, d->Cx, (long)d->H * d->W, d->x_ctot, as_stream(stream)); }
+    dim3 grid(cdiv(J, jt), cdiv(I, it), Z * ksplit);
     // algorithmic flops: every (output pixel, tap) pair that exists = same as the forward conv
     const double flops = 2.0 * d->Cy * d->Cx * d->KH * d->KW * (double)d->N * d->OH * d->OW;
-    return run<MODE_BWD_DATA>(tile, grid, p, as_stream(stream), flops);
+    rc = run<MODE_BWD_DATA>(tile, grid, p, as_stream(stream), flops);
+    if (rc == MGVAE_OK && ksplit > 1 && d->act != MGVAE_ACT_NONE)
+        act_slice(x + (size_t)d->x_coff * d->H * d->W, d->N, d->Cx, (long)d->H * d->W, d->x_ctot, d->act, d->slope, as_stream(stream));
+    return rc;
 }
 
 extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
@@ -475,10 +563,22 @@ extern "C" int mgvae_prof_enable(int on) {
     return MGVAE_OK;
 }
 
+static FILE* g_prof_detail = nullptr;
+extern "C" int mgvae_prof_detail(const char* path) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_detail) { fclose(g_prof_detail); g_prof_detail = nullptr; }
+    if (path && path[0]) {
+        g_prof_detail = fopen(path, "w");
+        if (!g_prof_detail) return MGVAE_EINVAL;
+        fprintf(g_prof_detail, "kind,tile,N,Cx,H,W,Cy,OH,OW,KH,KW,SH,SW,gx,gy,gz,us,gflop,tflops\n");
+    }
+    return MGVAE_OK;
+}
+
 extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    MgvaeProfRec recs[12];
-    for (int k = 0; k < 3; ++k)
+    MgvaeProfRec recs[20];
+    for (int k = 0; k < 5; ++k)
         for (int t = 0; t < 4; ++t) recs[k * 4 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
     for (auto& pe : g_prof_entries) {
         float ms = 0.f;
@@ -486,21 +586,30 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
         MgvaeProfRec& r = recs[pe.kind * 4 + pe.tile];
         r.launches += 1; r.ms += ms; r.flops += pe.flops;
+        if (g_prof_detail) {
+            const IgemmP& q = pe.p;
+            fprintf(g_prof_detail, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%u,%u,%u,%.1f,%.3f,%.2f\n", pe.kind, pe.tile, q.N, q.Cx,
+                    q.H, q.W, q.Cy, q.OH, q.OW, q.KH, q.KW, q.SH, q.SW, pe.gx, pe.gy, pe.gz, ms * 1e3, pe.flops * 1e-9,
+                    pe.flops / (ms * 1e-3) * 1e-12);
+        }
         hipEventDestroy(pe.e0); hipEventDestroy(pe.e1);
     }
     g_prof_entries.clear();
+    if (g_prof_detail) fflush(g_prof_detail);
     int n = 0;
-    for (int i = 0; i < 12 && n < cap; ++i)
+    for (int i = 0; i < 20 && n < cap; ++i)
         if (recs[i].launches > 0) out[n++] = recs[i];
     return n;
 }
 
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
-    static const char* names[12] = {
+    static const char* names[20] = {
         "igemm_kernel<0, 2, 2>", "igemm_kernel<0, 1, 2>", "igemm_kernel<0, 2, 1>", "igemm_kernel<0, 1, 1>",
         "igemm_kernel<1, 2, 2>", "igemm_kernel<1, 1, 2>", "igemm_kernel<1, 2, 1>", "igemm_kernel<1, 1, 1>",
-        "igemm_kernel<2, 2, 2>", "igemm_kernel<2, 1, 2>", "igemm_kernel<2, 2, 1>", "igemm_kernel<2, 1, 1>"};
-    if (kind < 0 || kind > 2 || tile < 0 || tile > 3) return "?";
+        "igemm_kernel<2, 2, 2>", "igemm_kernel<2, 1, 2>", "igemm_kernel<2, 2, 1>", "igemm_kernel<2, 1, 1>",
+        "dconv_kernel<2, 2> (fwd)", "dconv_kernel<1, 2> (fwd)", "dconv_kernel<2, 1> (fwd)", "dconv_kernel<1, 1> (fwd)",
+        "dconv_kernel<2, 2> (bwd_data)", "dconv_kernel<1, 2> (bwd_data)", "dconv_kernel<2, 1> (bwd_data)", "dconv_kernel<1, 1> (bwd_data)"};
+    if (kind < 0 || kind > 4 || tile < 0 || tile > 3) return "?";
     return names[kind * 4 + tile];
 }
 

@@ -33,6 +33,10 @@ SIGNATURES = {
     "mgvae_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_conv2d_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_conv2d_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
+    "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),
+    "mgvae_conv2d_fwd_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "mgvae_conv2d_bwd_data_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_channel_sum_accum": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "mgvae_instance_norm_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, P]),
     "mgvae_instance_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
@@ -58,6 +62,9 @@ SIGNATURES = {
     "mgvae_adam_step": (c_int, [P, P, P, P, c_size_t, P, c_float, c_float, P]),
     "mgvae_prof_enable": (c_int, [c_int]),
     "mgvae_prof_collect": (c_int, [ctypes.POINTER(ProfRec), c_int]),
+    "mgvae_prof_detail": (c_int, [ctypes.c_char_p]),
+    "mgvae_prof_record_begin": (c_int, [c_int, c_int, ctypes.c_double, P, ctypes.POINTER(P)]),
+    "mgvae_prof_record_end": (c_int, [P, P]),
     "mgvae_kernel_name": (ctypes.c_char_p, [c_int, c_int]),
 }
 

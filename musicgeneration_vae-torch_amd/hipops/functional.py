@@ -82,6 +82,33 @@ def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
     return nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], x_ctot, 0, y_ctot, 0, act, slope)
 
 
+USE_DIRECT = False  # direct (halo-tile, packed-weight) conv kernels; False = implicit-GEMM fallback only
+
+
+def _conv_fwd(d, x, w, b, y):
+    """Y = conv(X, Wt): direct kernel when the geometry is supported, else implicit GEMM"""
+    L = nat.lib()
+    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 0) if USE_DIRECT else 0
+    if n:
+        wp = torch.empty((n,), device=w.device, dtype=torch.float32)
+        nat.check(L.mgvae_conv_pack(ctypes.byref(d), 0, _p(w), _p(wp), _s()), "conv_pack")
+        nat.check(L.mgvae_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(wp), _p(b), _p(y), _s()), "conv2d_fwd_packed")
+    else:
+        nat.check(L.mgvae_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv2d_fwd")
+
+
+def _conv_bwd_data(d, y, w, b, x):
+    """X = conv_transpose(Y, Wt) (+bias): direct per-phase kernels when supported"""
+    L = nat.lib()
+    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 1) if USE_DIRECT else 0
+    if n:
+        wp = torch.empty((n,), device=w.device, dtype=torch.float32)
+        nat.check(L.mgvae_conv_pack(ctypes.byref(d), 1, _p(w), _p(wp), _s()), "conv_pack")
+        nat.check(L.mgvae_conv2d_bwd_data_packed(ctypes.byref(d), _p(y), _p(wp), _p(b), _p(x), _s()), "conv2d_bwd_data_packed")
+    else:
+        nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d), _p(y), _p(w), _p(b), _p(x), _s()), "conv2d_bwd_data")
+
+
 def _act_bwd(y, dy, act, slope):
     """dx = dy * act'(y) -> dense tensor"""
     y, yct = _sliceable(y)
@@ -109,7 +136,7 @@ class _ConvFn(torch.autograd.Function):
         y = out if out is not None else torch.empty((N, Cy, OH, OW), device=x.device, dtype=torch.float32)
         yct = _pitch(y)
         d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
-        nat.check(nat.lib().mgvae_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv2d_fwd")
+        _conv_fwd(d, x, w, b, y)
         ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.b = b
@@ -133,7 +160,7 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, Cx, H, W), device=dy.device, dtype=torch.float32)
             d2 = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, Cx, dct, ACT_NONE, 0.0)
-            nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), _s()), "conv2d_bwd_data")
+            _conv_bwd_data(d2, dy, w, None, dx)
         return dx, None, None, None, None, None, None, None
 
 
@@ -166,7 +193,7 @@ class _ConvTFn(torch.autograd.Function):
         yct = _pitch(y)
         # conv geometry: X = y (image side, Cx = Co), Y = x (feature side, Cy = Ci)
         d = _desc(N, Co, OH, OW, Ci, h, wd, (KH, KW), stride, pad, yct, xct, act, slope)
-        nat.check(nat.lib().mgvae_conv2d_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv_transpose2d_fwd")
+        _conv_bwd_data(d, x, w, b, y)
         ctx.geom = (N, Co, OH, OW, Ci, h, wd, (KH, KW), stride, pad, xct, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.b = b
@@ -190,7 +217,7 @@ class _ConvTFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, Ci, h, wd), device=dy.device, dtype=torch.float32)
             d2 = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, Ci, ACT_NONE, 0.0)
-            nat.check(L.mgvae_conv2d_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), _s()), "convT_bwd_data")
+            _conv_fwd(d2, dy, w, None, dx)
         return dx, None, None, None, None, None, None, None, None
 
 
