@@ -9,7 +9,10 @@
  *
  * Conventions
  *   - plain pointers + sizes; all tensors are fp32, NCHW, device memory owned by the
- *     caller (PyTorch's allocator); nothing is allocated, freed or retained here;
+ *     caller (PyTorch's allocator); the library allocates nothing per call -- its only own
+ *     memory is a small cache of per-geometry gather tables (a few hundred KB in total)
+ *     filled on the first call of each conv geometry (run one warm-up step before
+ *     capturing a hipGraph);
  *   - every call only enqueues work on `stream` (a hipStream_t passed as void*);
  *     no implicit synchronisation, safe under hipGraph stream capture;
  *   - return 0 on success, a negative MGVAE_E* code otherwise (mgvae_strerror());

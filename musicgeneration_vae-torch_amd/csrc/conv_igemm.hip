@@ -14,6 +14,8 @@
 // conflict-free.
 #include "mgvae_common.h"
 #include <cstdio>
+#include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -34,6 +36,9 @@ struct IgemmP {
     float slope;
     int kchunk;         // bwd_weight: pixels per split
     int ksplit;         // fwd / bwd_data: K splits (blockIdx.z = phase * ksplit + split); >1 => atomic epilogue
+    const int2* ktab;   // fwd / bwd_data: per-K gather table {src offset, dh | dw << 16}; bwd_data: [phase][stride]
+    const int* wtab;    // bwd_data: per-K weight offset (cy * Cx * KH*KW + tap), [phase][stride]
+    int ktab_stride;    // entries per phase (padded by 16 so a wave can always read its whole row group)
 };
 
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
@@ -88,9 +93,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     constexpr int NA = IT * BK / 256, NB = JT * BK / 256;
 
     __shared__ float lds[2 * (A_ELEMS + B_ELEMS)];
-    __shared__ int tap_off[16];   // source offset of a tap
-    __shared__ int tap_dh[16], tap_dw[16];
-    __shared__ int tap_w[16];     // bwd_data: offset of the tap inside a KHxKW weight slice
     float* As0 = lds;
     float* Bs0 = lds + 2 * A_ELEMS;
 
@@ -113,10 +115,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         split = blockIdx.z;
         const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
         kbeg = split * kc; kend = min(Ktot, kbeg + kc);
-        if (tid < T) {
-            const int kh = tid / p.KW, kw = tid - kh * p.KW;
-            tap_dh[tid] = kh; tap_dw[tid] = kw; tap_off[tid] = kh * p.W + kw;
-        }
     } else if constexpr (MODE == MODE_BWD_DATA) {
         const int ph = blockIdx.z / p.ksplit;
         split = blockIdx.z - ph * p.ksplit;
@@ -135,34 +133,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             if (split > 0 && kbeg >= Ktot) return;   // nothing left for this split (split 0 still writes bias)
         }
         if (Jtot == 0 || j0 >= Jtot) return;   // uniform across the workgroup
-        if (tid < T) {
-            const int jh = tid / nkw, jw = tid - jh * nkw;
-            tap_dh[tid] = qh - jh; tap_dw[tid] = qw - jw;
-            tap_off[tid] = (qh - jh) * p.OW + (qw - jw);
-            tap_w[tid] = (kh0 + p.SH * jh) * p.KW + kw0 + p.SW * jw;
-        }
-        if (T == 0) { T = 1; kbeg = 0; kend = 0; }   // no taps: loop never runs, keep divisions defined
+        (void)qh; (void)qw;
+        if (T == 0) { T = 1; kbeg = 0; kend = 0; }   // no taps: loop never runs
     } else {
         Itot = p.Cy; Jtot = p.Cx * p.KH * p.KW; T = 1;
         kbeg = blockIdx.z * p.kchunk;
         kend = min(p.N * P, kbeg + p.kchunk);
     }
-    __syncthreads();
+    const int2* __restrict__ ktab = p.ktab;
+    const int* __restrict__ wtab = p.wtab;
+    if constexpr (MODE == MODE_BWD_DATA) {
+        ktab += (size_t)(blockIdx.z / p.ksplit) * p.ktab_stride;
+        wtab += (size_t)(blockIdx.z / p.ksplit) * p.ktab_stride;
+    }
 
     // ---------------- loader state ------------------------------------------------------
     // "lanes along j/i" mapping (KJ / KI images): each wave-instruction covers 64 columns
     // of one K row; the K row is wave-uniform.
+    // Each wave owns a CONTIGUOUS group of K rows, so its gather constants are one scalar load.
     constexpr int JC = JT / 64, IC = IT / 64;
-    const int jc = wave % JC, jkr0 = wave / JC;   constexpr int jkstep = 4 / JC;
-    const int ic = wave % IC, ikr0 = wave / IC;   constexpr int ikstep = 4 / IC;
+    const int jc = wave % JC, jkr0 = (wave / JC) * NB;
+    const int ic = wave % IC, ikr0 = (wave / IC) * NA;
     // "lanes along k" mapping (IK / JK images): 16 lanes per row, 16 rows per pass.
     const int kl = tid & 15, rr = tid >> 4;
 
     // B gather state (FWD: from X; BWD_DATA: from Y)
-    bool bj_valid = false; int b_pix = 0, b_r0 = 0, b_c0 = 0, b_RH = 1, b_RW = 1, b_cstride = 0;
-    ChanTap bk; bk.c = 0; bk.t = 0;
+    bool bj_valid = false; int b_pix = 0, b_r0 = 0, b_c0 = 0, b_RH = 1, b_RW = 1;
     // A gather state (BWD_DATA weights)
-    ChanTap ak; ak.c = 0; ak.t = 0;
     bool ai_valid = false; int a_i = 0;
     // BWD_WEIGHT state
     int w_n = 0, w_p = 0;                      // running pixel of this thread's k lane
@@ -177,8 +174,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         const int oh = pp / p.OW, ow = pp - oh * p.OW;
         b_r0 = oh * p.SH - p.PH; b_c0 = ow * p.SW - p.PW;
         b_pix = (n * p.x_ctot + p.x_coff) * HW + b_r0 * p.W + b_c0;
-        b_RH = p.H; b_RW = p.W; b_cstride = HW;
-        bk.init(kbeg + jkr0, T);
+        b_RH = p.H; b_RW = p.W;
     } else if constexpr (MODE == MODE_BWD_DATA) {
         const int j = j0 + jc * 64 + lane;
         bj_valid = j < Jtot;
@@ -187,11 +183,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         const int a = pp / Wb, b = pp - a * Wb;
         b_r0 = a; b_c0 = b;
         b_pix = (n * p.y_ctot + p.y_coff) * P + a * p.OW + b;
-        b_RH = p.OH; b_RW = p.OW; b_cstride = P;
-        bk.init(kbeg + jkr0, T);
+        b_RH = p.OH; b_RW = p.OW;
         a_i = i0 + ic * 64 + lane;
         ai_valid = a_i < Itot;
-        ak.init(kbeg + ikr0, T);
     } else {
         const int kp = kbeg + kl;
         w_n = kp / P; w_p = kp - w_n * P;
@@ -212,23 +206,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 
     float ra[NA], rb[NB];
 
+    // All loads are UNCONDITIONAL with a clamped address and a select afterwards, so the compiler
+    // emits one straight-line block: every global load of a K tile is in flight together (a
+    // predicated load would be a branch + wait per element).  The per-K gather constants come from
+    // the ktab table through scalar loads (the K row is wave-uniform).
     auto load_tile = [&](int k0) {
         // ------------------------------ A operand ------------------------------
         if constexpr (MODE == MODE_FWD) {
             const int gk = k0 + kl;
+            const bool kok = gk < kend;
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const int gi = i0 + rr + 16 * r;
-                ra[r] = (gi < Itot && gk < kend) ? p.Wt[(size_t)gi * Ktot + gk] : 0.f;
+                const bool ok = kok && gi < Itot;
+                const float v = p.Wt[ok ? (size_t)gi * Ktot + gk : 0];
+                ra[r] = ok ? v : 0.f;
             }
         } else if constexpr (MODE == MODE_BWD_DATA) {
             const int KK = p.KH * p.KW;
+            const int ai_off = a_i * KK;
+            const int* __restrict__ wt = wtab + (k0 + ikr0);
+            int wo[NA];
+#pragma unroll
+            for (int r = 0; r < NA; ++r) wo[r] = wt[r];          // one scalar load (rows are contiguous)
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
-                const int k = k0 + ikr0 + ikstep * r;
-                const bool ok = ai_valid && k < kend;
-                ra[r] = ok ? p.Wt[((size_t)ak.c * p.Cx + a_i) * KK + tap_w[ak.t]] : 0.f;
-                ak.advance(ikstep, T);
+                const bool ok = ai_valid && (k0 + ikr0 + r) < kend;
+                const float v = p.Wt[ok ? wo[r] + ai_off : 0];
+                ra[r] = ok ? v : 0.f;
             }
         } else {
             const bool kok = (k0 + kl) < kend;
@@ -236,21 +241,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const int gi = i0 + rr + 16 * r;
-                ra[r] = (kok && gi < Itot) ? p.Y[base + gi * P] : 0.f;
+                const bool ok = kok && gi < Itot;
+                const float v = p.Y[ok ? base + gi * P : 0];
+                ra[r] = ok ? v : 0.f;
             }
         }
         // ------------------------------ B operand ------------------------------
         if constexpr (MODE != MODE_BWD_WEIGHT) {
             const float* __restrict__ src = (MODE == MODE_FWD) ? p.X : p.Y;
+            const int2* __restrict__ kt = ktab + (k0 + jkr0);
+            int2 e[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) e[r] = kt[r];           // one scalar load (rows are contiguous)
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const int k = k0 + jkr0 + jkstep * r;
-                const int t = bk.t;
-                const bool ok = bj_valid && k < kend &&
-                                (unsigned)(b_r0 + tap_dh[t]) < (unsigned)b_RH &&
-                                (unsigned)(b_c0 + tap_dw[t]) < (unsigned)b_RW;
-                rb[r] = ok ? src[b_pix + bk.c * b_cstride + tap_off[t]] : 0.f;
-                bk.advance(jkstep, T);
+                const int dh = (int)(short)(e[r].y & 0xffff), dw = e[r].y >> 16;
+                const bool ok = bj_valid && (k0 + jkr0 + r) < kend && (unsigned)(b_r0 + dh) < (unsigned)b_RH &&
+                                (unsigned)(b_c0 + dw) < (unsigned)b_RW;
+                const float v = src[ok ? b_pix + e[r].x : 0];
+                rb[r] = ok ? v : 0.f;
             }
         } else {
             const bool kok = (k0 + kl) < kend;
@@ -261,7 +270,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             for (int r = 0; r < NB; ++r) {
                 const bool ok = kok && (unsigned)(r0 + bj_dh[r]) < (unsigned)p.H &&
                                 (unsigned)(c0 + bj_dw[r]) < (unsigned)p.W;
-                rb[r] = ok ? p.X[base + bj_off[r]] : 0.f;
+                const float v = p.X[ok ? base + bj_off[r] : 0];
+                rb[r] = ok ? v : 0.f;
             }
             // advance this thread's pixel by one K tile
             w_p += BK;
@@ -277,11 +287,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             for (int r = 0; r < NA; ++r) As[(rr + 16 * r) * LDP + kl] = ra[r];
         } else {
 #pragma unroll
-            for (int r = 0; r < NA; ++r) As[(ikr0 + ikstep * r) * IT + ic * 64 + lane] = ra[r];
+            for (int r = 0; r < NA; ++r) As[(ikr0 + r) * IT + ic * 64 + lane] = ra[r];
         }
         if constexpr (B_KJ) {
 #pragma unroll
-            for (int r = 0; r < NB; ++r) Bs[(jkr0 + jkstep * r) * JT + jc * 64 + lane] = rb[r];
+            for (int r = 0; r < NB; ++r) Bs[(jkr0 + r) * JT + jc * 64 + lane] = rb[r];
         } else {
 #pragma unroll
             for (int r = 0; r < NB; ++r) Bs[(rr + 16 * r) * LDP + kl] = rb[r];
@@ -405,8 +415,82 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.N = d->N; p.Cx = d->Cx; p.H = d->H; p.W = d->W; p.Cy = d->Cy; p.OH = d->OH; p.OW = d->OW;
     p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
-    p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1;
+    p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0;
     return p;
+}
+
+// ---- per-geometry gather tables (device-resident, built once per geometry and cached) -----------
+// One int4 per K index: {source offset (channel + tap), tap row offset, tap col offset, weight
+// offset}.  The kernels read them with scalar loads.  This is the only memory the library owns:
+// a few hundred KB in total, allocated on the first call of a geometry (so run one warm-up step
+// before capturing a hipGraph).
+struct KtabKey {
+    int v[14];
+    bool operator<(const KtabKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+struct KtabVal { int2* dev; int* wdev; int stride; };
+static std::map<KtabKey, KtabVal> g_ktab;
+static std::mutex g_ktab_mu;
+
+static inline int2 kt_entry(int off, int dh, int dw) { return make_int2(off, (dh & 0xffff) | (dw << 16)); }
+
+static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p) {
+    KtabKey key{{mode, d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, 0}};
+    std::lock_guard<std::mutex> lk(g_ktab_mu);
+    auto it = g_ktab.find(key);
+    if (it == g_ktab.end()) {
+        std::vector<int2> host;
+        std::vector<int> whost;
+        int str = 0;
+        const int KK = d->KH * d->KW;
+        if (mode == MODE_FWD) {
+            str = d->Cx * KK + 16;
+            host.assign(str, make_int2(0, 0));
+            for (int c = 0; c < d->Cx; ++c)
+                for (int t = 0; t < KK; ++t) {
+                    const int kh = t / d->KW, kw = t % d->KW;
+                    host[(size_t)c * KK + t] = kt_entry(c * d->H * d->W + kh * d->W + kw, kh, kw);
+                }
+        } else {
+            const int Z = d->SH * d->SW;
+            int maxT = 1;
+            for (int ph = 0; ph < Z; ++ph) {
+                const int rh = ph / d->SW, rw = ph % d->SW;
+                const int kh0 = (rh + d->PH) % d->SH, kw0 = (rw + d->PW) % d->SW;
+                const int nkh = kh0 < d->KH ? (d->KH - kh0 + d->SH - 1) / d->SH : 0;
+                const int nkw = kw0 < d->KW ? (d->KW - kw0 + d->SW - 1) / d->SW : 0;
+                if (nkh * nkw > maxT) maxT = nkh * nkw;
+            }
+            str = d->Cy * maxT + 16;
+            host.assign((size_t)Z * str, make_int2(0, 0));
+            whost.assign((size_t)Z * str, 0);
+            for (int ph = 0; ph < Z; ++ph) {
+                const int rh = ph / d->SW, rw = ph % d->SW;
+                const int kh0 = (rh + d->PH) % d->SH, kw0 = (rw + d->PW) % d->SW;
+                const int nkh = kh0 < d->KH ? (d->KH - kh0 + d->SH - 1) / d->SH : 0;
+                const int nkw = kw0 < d->KW ? (d->KW - kw0 + d->SW - 1) / d->SW : 0;
+                const int qh = (rh + d->PH - kh0) / d->SH, qw = (rw + d->PW - kw0) / d->SW;
+                const int T = nkh * nkw;
+                for (int c = 0; c < d->Cy; ++c)
+                    for (int t = 0; t < T; ++t) {
+                        const int jh = t / nkw, jw = t % nkw;
+                        const size_t idx = (size_t)ph * str + (size_t)c * T + t;
+                        host[idx] = kt_entry(c * d->OH * d->OW + (qh - jh) * d->OW + (qw - jw), qh - jh, qw - jw);
+                        whost[idx] = c * d->Cx * KK + (kh0 + d->SH * jh) * d->KW + kw0 + d->SW * jw;
+                    }
+            }
+        }
+        KtabVal v{nullptr, nullptr, str};
+        if (hipMalloc(&v.dev, host.size() * sizeof(int2)) != hipSuccess) return MGVAE_ELAUNCH;
+        if (hipMemcpy(v.dev, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) return MGVAE_ELAUNCH;
+        if (!whost.empty()) {
+            if (hipMalloc(&v.wdev, whost.size() * sizeof(int)) != hipSuccess) return MGVAE_ELAUNCH;
+            if (hipMemcpy(v.wdev, whost.data(), whost.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return MGVAE_ELAUNCH;
+        }
+        it = g_ktab.emplace(key, v).first;
+    }
+    p.ktab = it->second.dev; p.wtab = it->second.wdev; p.ktab_stride = it->second.stride;
+    return MGVAE_OK;
 }
 
 // tile ids: 0 = 128x128, 1 = 64(i)x128(j), 2 = 128(i)x64(j), 3 = 64x64.
@@ -493,6 +577,8 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     if (!x || !w || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
     p.X = x; p.Wt = w; p.bias = bias; p.out = y; p.Y = nullptr;
+    rc = get_ktab(d, MODE_FWD, p);
+    if (rc) return rc;
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
     int ksplit = 1;
     const int tile = pick_tile(I, J, 1, (long)d->Cx * d->KH * d->KW, &ksplit);
@@ -513,6 +599,8 @@ extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, con
     if (!x || !w || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
     p.Y = y; p.Wt = w; p.bias = bias; p.out = x; p.X = nullptr;
+    rc = get_ktab(d, MODE_BWD_DATA, p);
+    if (rc) return rc;
     const int Z = d->SH * d->SW;
     const long I = d->Cx;
     const long J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
