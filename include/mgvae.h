@@ -71,6 +71,11 @@ int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, con
  * 73-77,116-120): X = conv_transpose(Y, Wt) (+ bias[Cx]), stride-phase decomposed    */
 int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
                           float* x, void* stream);
+/* Same result from w_t = mgvae_weight_transpose(w) ([Cy][KH*KW][Cx]): the weight operand then
+ * loads contiguously along the lanes.  The transpose is one small HBM pass per call.            */
+int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx, int KK, void* stream);
+int mgvae_conv2d_bwd_data_tw(const MgvaeConvDesc* d, const float* y, const float* w_t, const float* bias,
+                             float* x, void* stream);
 /* dWt += corr(X, Y): weight gradient of either layer type (split-K, fp32 atomics)    */
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                             void* stream);

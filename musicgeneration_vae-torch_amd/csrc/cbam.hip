@@ -87,14 +87,18 @@ __global__ __launch_bounds__(256) void cbam_chan_mlp_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------- F3: spatial pooling
-// 64 pixels x 4 channel groups per workgroup; pixels on the lanes (coalesced in NCHW)
+// PXB pixels x (256/PXB) channel groups per workgroup; pixels run along the lanes (coalesced in
+// NCHW).  PXB shrinks for small maps so the launch still fills the chip and the per-thread
+// channel loop stays short.
+template <int PXB>
 __global__ __launch_bounds__(256) void cbam_spatial_pool_kernel(const float* __restrict__ u, const float* __restrict__ cg,
                                                                 float* __restrict__ s_in, int* __restrict__ amax_c,
                                                                 int N, int C, int P) {
-    __shared__ float ssum[4][64], smax[4][64];
-    __shared__ int sidx[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long gp = (long)blockIdx.x * 64 + lane;
+    constexpr int CGB = 256 / PXB;
+    __shared__ float ssum[CGB][PXB], smax[CGB][PXB];
+    __shared__ int sidx[CGB][PXB];
+    const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
+    const long gp = (long)blockIdx.x * PXB + px;
     const bool ok = gp < (long)N * P;
     const int n = ok ? (int)(gp / P) : 0, pp = ok ? (int)(gp - (long)n * P) : 0;
     float s = 0.f, m = -INFINITY;
@@ -102,26 +106,33 @@ __global__ __launch_bounds__(256) void cbam_spatial_pool_kernel(const float* __r
     if (ok) {
         const float* up = u + (size_t)n * C * P + pp;
         const float* gp_ = cg + (size_t)n * C;
-        for (int c = grp; c < C; c += 4) {
+        for (int c = grp; c < C; c += CGB) {
             const float v = up[(size_t)c * P] * gp_[c];
             s += v;
             if (v > m) { m = v; mi = c; }
         }
     }
-    ssum[grp][lane] = s; smax[grp][lane] = m; sidx[grp][lane] = mi;
+    ssum[grp][px] = s; smax[grp][px] = m; sidx[grp][px] = mi;
     __syncthreads();
     if (grp == 0 && ok) {
-        float ts = ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
-        float tm = smax[0][lane]; int ti = sidx[0][lane];
-#pragma unroll
-        for (int g = 1; g < 4; ++g) {
-            const float om = smax[g][lane]; const int oi = sidx[g][lane];
+        float ts = 0.f, tm = -INFINITY; int ti = 0x7fffffff;
+#pragma unroll 4
+        for (int g = 0; g < CGB; ++g) {
+            ts += ssum[g][px];
+            const float om = smax[g][px]; const int oi = sidx[g][px];
             if (om > tm || (om == tm && oi < ti)) { tm = om; ti = oi; }
         }
         s_in[(size_t)n * 2 * P + pp] = ts / (float)C;
         s_in[(size_t)n * 2 * P + P + pp] = tm;
         amax_c[(size_t)n * P + pp] = ti;
     }
+}
+
+static inline int pick_pxb(long total_px) {
+    if (total_px >= 64 * 512) return 64;
+    if (total_px >= 32 * 512) return 32;
+    if (total_px >= 16 * 256) return 16;
+    return 8;
 }
 
 // ---------------------------------------------------------------- F4: 3x3 conv (2->1) + sigmoid
@@ -172,14 +183,16 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
 
 // ================================================================ backward
 // B1: dt[n,p] = (sum_c g * u * cg) * sg * (1 - sg),  g = dy * act'(y)
+template <int PXB>
 __global__ __launch_bounds__(256) void cbam_bwd_spatial_kernel(const float* __restrict__ u, const float* __restrict__ y,
                                                                const float* __restrict__ dy, const float* __restrict__ cg,
                                                                const float* __restrict__ sg, float* __restrict__ dt,
                                                                int N, int C, int P, int y_ctot, int y_coff, int mode,
                                                                int act, float slope) {
-    __shared__ float ssum[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const long gp = (long)blockIdx.x * 64 + lane;
+    constexpr int CGB = 256 / PXB;
+    __shared__ float ssum[CGB][PXB];
+    const int px = threadIdx.x % PXB, grp = threadIdx.x / PXB;
+    const long gp = (long)blockIdx.x * PXB + px;
     const bool ok = gp < (long)N * P;
     const int n = ok ? (int)(gp / P) : 0, pp = ok ? (int)(gp - (long)n * P) : 0;
     float s = 0.f;
@@ -188,16 +201,18 @@ __global__ __launch_bounds__(256) void cbam_bwd_spatial_kernel(const float* __re
         const float* yp = y + ((size_t)n * y_ctot + y_coff) * P + pp;
         const float* dyp = dy + ((size_t)n * y_ctot + y_coff) * P + pp;
         const float* gp_ = cg + (size_t)n * C;
-        for (int c = grp; c < C; c += 4) {
+        for (int c = grp; c < C; c += CGB) {
             float g = dyp[(size_t)c * P];
             if (mode != 0) g *= act_grad_from_out(yp[(size_t)c * P], act, slope);
             s += g * (up[(size_t)c * P] * gp_[c]);
         }
     }
-    ssum[grp][lane] = s;
+    ssum[grp][px] = s;
     __syncthreads();
     if (grp == 0 && ok) {
-        const float t = ssum[0][lane] + ssum[1][lane] + ssum[2][lane] + ssum[3][lane];
+        float t = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < CGB; ++g) t += ssum[g][px];
         const float sgg = sg[gp];
         dt[gp] = t * sgg * (1.f - sgg);
     }
@@ -286,19 +301,20 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_kernel(
     if (lane == 0) dcg[nc] = acc;
 }
 
-// B4: MLP backward, one workgroup per sample.  dynamic LDS: dpre[C], ha,hm,dha,dhm[Cr]
-__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restrict__ dcg, const float* __restrict__ cg,
-                                                           const float* __restrict__ hid, const float* __restrict__ avg,
-                                                           const float* __restrict__ mx, const float* __restrict__ w1,
-                                                           const float* __restrict__ w2, float* __restrict__ dw1,
-                                                           float* __restrict__ dw2, float* __restrict__ davg,
-                                                           float* __restrict__ dmaxp, int C) {
+// B4a: MLP backward per sample (no weight gradients here).  dynamic LDS: dpre[C], ha,hm,dha,dhm[Cr]
+// writes dpre[N,C] (over dcg), dh[N,2,Cr], davg[N,C], dmaxp[N,C]
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(float* __restrict__ dcg, const float* __restrict__ cg,
+                                                           const float* __restrict__ hid, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, float* __restrict__ dh,
+                                                           float* __restrict__ davg, float* __restrict__ dmaxp, int C) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Cr = C / 16, n = blockIdx.x, tid = threadIdx.x;
     float* dpre = sm; float* ha = sm + C; float* hm = ha + Cr; float* dha = hm + Cr; float* dhm = dha + Cr;
     for (int c = tid; c < C; c += 256) {
         const float g = cg[(size_t)n * C + c];
-        dpre[c] = dcg[(size_t)n * C + c] * g * (1.f - g);
+        const float v = dcg[(size_t)n * C + c] * g * (1.f - g);
+        dpre[c] = v;
+        dcg[(size_t)n * C + c] = v;           // dcg now holds dpre for the weight-gradient kernel
     }
     for (int j = tid; j < Cr; j += 256) { ha[j] = hid[(size_t)n * 2 * Cr + j]; hm[j] = hid[(size_t)n * 2 * Cr + Cr + j]; }
     __syncthreads();
@@ -307,7 +323,11 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restri
         float s = 0.f;
         for (int c = lane; c < C; c += 64) s += w2[(size_t)c * Cr + j] * dpre[c];
         s = wave_sum(s);
-        if (lane == 0) { dha[j] = ha[j] > 0.f ? s : 0.f; dhm[j] = hm[j] > 0.f ? s : 0.f; }
+        if (lane == 0) {
+            const float a = ha[j] > 0.f ? s : 0.f, m = hm[j] > 0.f ? s : 0.f;
+            dha[j] = a; dhm[j] = m;
+            dh[(size_t)n * 2 * Cr + j] = a; dh[(size_t)n * 2 * Cr + Cr + j] = m;
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -318,18 +338,29 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restri
         }
         davg[(size_t)n * C + c] = da; dmaxp[(size_t)n * C + c] = dm;
     }
-    // weight gradients: flat index on the lanes so each atomic wave-instruction is 256 contiguous bytes
-    const int tot = C * Cr;
-    if (dw1)
-        for (int f = tid; f < tot; f += 256) {
-            const int j = f / C, c = f - j * C;
-            atomicAdd(&dw1[f], dha[j] * avg[(size_t)n * C + c] + dhm[j] * mx[(size_t)n * C + c]);
-        }
-    if (dw2)
-        for (int f = tid; f < tot; f += 256) {
-            const int c = f / Cr, j = f - c * Cr;
-            atomicAdd(&dw2[f], dpre[c] * (ha[j] + hm[j]));
-        }
+}
+
+// B4b: weight gradients as a batched reduction over the samples; one thread owns one (c, j)
+// pair of BOTH matrices, so the accumulation into the gradient needs no atomics.
+//   dw2[c][j] += sum_n dpre[n,c] * (ha[n,j] + hm[n,j])
+//   dw1[j][c] += sum_n dha[n,j] * avg[n,c] + dhm[n,j] * max[n,c]
+__global__ __launch_bounds__(256) void cbam_bwd_mlp_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ hid,
+                                                                 const float* __restrict__ dh, const float* __restrict__ avg,
+                                                                 const float* __restrict__ mx, float* __restrict__ dw1,
+                                                                 float* __restrict__ dw2, int N, int C) {
+    const int Cr = C / 16;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= C * Cr) return;
+    const int c = f / Cr, j = f - c * Cr;
+    float a2 = 0.f, a1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* hn = hid + (size_t)n * 2 * Cr;
+        const float* dn = dh + (size_t)n * 2 * Cr;
+        a2 += dpre[(size_t)n * C + c] * (hn[j] + hn[Cr + j]);
+        a1 += dn[j] * avg[(size_t)n * C + c] + dn[Cr + j] * mx[(size_t)n * C + c];
+    }
+    if (dw2) dw2[(size_t)c * Cr + j] += a2;
+    if (dw1) dw1[(size_t)j * C + c] += a1;
 }
 
 // B5: du += davg/P + [p == argmax_hw] dmaxp
@@ -348,7 +379,7 @@ __global__ __launch_bounds__(256) void cbam_bwd_finish_kernel(float* __restrict_
 // ================================================================ host entry points
 extern "C" size_t mgvae_cbam_save_floats(int N, int C, int H, int W) { return cbam_save_floats(N, C, H * W); }
 extern "C" size_t mgvae_cbam_bwd_scratch_floats(int N, int C, int H, int W) {
-    return (size_t)3 * N * H * W + (size_t)3 * N * C;
+    return (size_t)3 * N * H * W + (size_t)3 * N * C + (size_t)2 * N * (C / 16);
 }
 
 static int cbam_check(int N, int C, int H, int W, int ctot, int coff, int mode, int act) {
@@ -371,8 +402,12 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
     hipLaunchKernelGGL(cbam_chan_pool_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, sv.avg, sv.mx, sv.amax_hw, NC, P);
     hipLaunchKernelGGL(cbam_chan_mlp_kernel, dim3(N), dim3(256), (2 * C + 2 * Cr) * sizeof(float), s, sv.avg, sv.mx,
                        w1, w2, sv.hid, sv.cg, C);
-    hipLaunchKernelGGL(cbam_spatial_pool_kernel, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, sv.cg, sv.s_in,
-                       sv.amax_c, N, C, P);
+    switch (pick_pxb((long)N * P)) {
+        case 64: hipLaunchKernelGGL(cbam_spatial_pool_kernel<64>, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
+        case 32: hipLaunchKernelGGL(cbam_spatial_pool_kernel<32>, dim3(cdiv((long)N * P, 32)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
+        case 16: hipLaunchKernelGGL(cbam_spatial_pool_kernel<16>, dim3(cdiv((long)N * P, 16)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
+        default: hipLaunchKernelGGL(cbam_spatial_pool_kernel<8>, dim3(cdiv((long)N * P, 8)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
+    }
     hipLaunchKernelGGL(cbam_spatial_gate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, sv.s_in, wsp, sv.sg, N, H, W);
     const long total = (long)NC * P;
     const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
@@ -397,14 +432,22 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     float* dcg = scratch + (size_t)3 * N * P;    // [N,C]
     float* davg = dcg + NC;
     float* dmaxp = davg + NC;
-    hipLaunchKernelGGL(cbam_bwd_spatial_kernel, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt,
-                       N, C, P, y_ctot, y_coff, mode, act, slope);
+    float* dh = dmaxp + NC;                      // [N,2,Cr]
+    switch (pick_pxb((long)N * P)) {
+        case 64: hipLaunchKernelGGL(cbam_bwd_spatial_kernel<64>, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt, N, C, P, y_ctot, y_coff, mode, act, slope); break;
+        case 32: hipLaunchKernelGGL(cbam_bwd_spatial_kernel<32>, dim3(cdiv((long)N * P, 32)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt, N, C, P, y_ctot, y_coff, mode, act, slope); break;
+        case 16: hipLaunchKernelGGL(cbam_bwd_spatial_kernel<16>, dim3(cdiv((long)N * P, 16)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt, N, C, P, y_ctot, y_coff, mode, act, slope); break;
+        default: hipLaunchKernelGGL(cbam_bwd_spatial_kernel<8>, dim3(cdiv((long)N * P, 8)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt, N, C, P, y_ctot, y_coff, mode, act, slope); break;
+    }
     hipLaunchKernelGGL(cbam_bwd_sgate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, dt, sv.s_in, wsp, ds_in,
                        dwsp, N, H, W);
     hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
                        sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
     hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(N), dim3(256), (C + 4 * Cr) * sizeof(float), s, dcg, sv.cg, sv.hid,
-                       sv.avg, sv.mx, w1, w2, dw1, dw2, davg, dmaxp, C);
+                       w1, w2, dh, davg, dmaxp, C);
+    if (dw1 || dw2)
+        hipLaunchKernelGGL(cbam_bwd_mlp_wgrad_kernel, dim3(cdiv((long)C * Cr, 256)), dim3(256), 0, s, dcg, sv.hid, dh, sv.avg,
+                           sv.mx, dw1, dw2, N, C);
     const long total = (long)NC * P;
     const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(cbam_bwd_finish_kernel, dim3(blocks), dim3(256), 0, s, du, davg, dmaxp, sv.amax_hw, total, P);

@@ -39,6 +39,7 @@ struct IgemmP {
     const int2* ktab;   // fwd / bwd_data: per-K gather table {src offset, dh | dw << 16}; bwd_data: [phase][stride]
     const int* wtab;    // bwd_data: per-K weight offset (cy * Cx * KH*KW + tap), [phase][stride]
     int ktab_stride;    // entries per phase (padded by 16 so a wave can always read its whole row group)
+    int w_transposed;   // bwd_data: Wt is [Cy][KH*KW][Cx] (mgvae_weight_transpose) -> lane-contiguous A loads
 };
 
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             }
         } else if constexpr (MODE == MODE_BWD_DATA) {
             const int KK = p.KH * p.KW;
-            const int ai_off = a_i * KK;
+            const int ai_off = p.w_transposed ? a_i : a_i * KK;
             const int* __restrict__ wt = wtab + (k0 + ikr0);
             int wo[NA];
 #pragma unroll
@@ -415,7 +416,7 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.N = d->N; p.Cx = d->Cx; p.H = d->H; p.W = d->W; p.Cy = d->Cy; p.OH = d->OH; p.OW = d->OW;
     p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
-    p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0;
+    p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0; p.w_transposed = 0;
     return p;
 }
 
@@ -434,8 +435,8 @@ static std::mutex g_ktab_mu;
 
 static inline int2 kt_entry(int off, int dh, int dw) { return make_int2(off, (dh & 0xffff) | (dw << 16)); }
 
-static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p) {
-    KtabKey key{{mode, d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, 0}};
+static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0) {
+    KtabKey key{{mode + 16 * wtrans, d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, 0}};
     std::lock_guard<std::mutex> lk(g_ktab_mu);
     auto it = g_ktab.find(key);
     if (it == g_ktab.end()) {
@@ -476,7 +477,8 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p) {
                         const int jh = t / nkw, jw = t % nkw;
                         const size_t idx = (size_t)ph * str + (size_t)c * T + t;
                         host[idx] = kt_entry(c * d->OH * d->OW + (qh - jh) * d->OW + (qw - jw), qh - jh, qw - jw);
-                        whost[idx] = c * d->Cx * KK + (kh0 + d->SH * jh) * d->KW + kw0 + d->SW * jw;
+                        const int tapw = (kh0 + d->SH * jh) * d->KW + kw0 + d->SW * jw;
+                        whost[idx] = wtrans ? (c * KK + tapw) * d->Cx : c * d->Cx * KK + tapw;
                     }
             }
         }
@@ -592,14 +594,15 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     return rc;
 }
 
-extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
-                                     float* x, void* stream) {
+static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias, float* x,
+                         void* stream, int wtrans) {
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !w || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
     p.Y = y; p.Wt = w; p.bias = bias; p.out = x; p.X = nullptr;
-    rc = get_ktab(d, MODE_BWD_DATA, p);
+    rc = get_ktab(d, MODE_BWD_DATA, p, wtrans);
+    p.w_transposed = wtrans;
     if (rc) return rc;
     const int Z = d->SH * d->SW;
     const long I = d->Cx;
@@ -620,6 +623,41 @@ extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, con
     return rc;
 }
 
+extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
+                                     float* x, void* stream) {
+    return bwd_data_impl(d, y, w, bias, x, stream, 0);
+}
+
+// same with w_t = mgvae_weight_transpose(w): [Cy][KH*KW][Cx], so the weight operand loads are
+// contiguous along the lanes (the [Cy][Cx][KH][KW] layout strides them by KH*KW floats)
+extern "C" int mgvae_conv2d_bwd_data_tw(const MgvaeConvDesc* d, const float* y, const float* w_t, const float* bias,
+                                        float* x, void* stream) {
+    return bwd_data_impl(d, y, w_t, bias, x, stream, 1);
+}
+
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                               int Cy, int Cx, int KK) {
+    // out[cy][kk][cx] = in[cy][cx][kk]; a workgroup moves a [64 cx][KK] slab of one cy through LDS
+    extern __shared__ float tile[];
+    const int cy = blockIdx.y, cx0 = blockIdx.x * 64;
+    const int n = min(64, Cx - cx0);
+    const float* src = w + ((size_t)cy * Cx + cx0) * KK;
+    for (int e = threadIdx.x; e < n * KK; e += 256) tile[e] = src[e];      // contiguous read
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * KK; e += 256) {
+        const int kk = e / n, c = e - kk * n;
+        wt[((size_t)cy * KK + kk) * Cx + cx0 + c] = tile[c * KK + kk];     // contiguous write per kk row
+    }
+}
+
+extern "C" int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx, int KK, void* stream) {
+    if (!w || !w_t || Cy <= 0 || Cx <= 0 || KK <= 0 || KK > 64) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3(cdiv(Cx, 64), Cy), dim3(256), 64 * KK * sizeof(float), as_stream(stream),
+                       w, w_t, Cy, Cx, KK);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
 extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                                        void* stream) {
     int rc = validate(d);
@@ -628,13 +666,16 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
     IgemmP p = make_params(d);
     p.X = x; p.Y = y; p.out = dw; p.Wt = nullptr; p.bias = nullptr;
     const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
+    // big tiles always (they run ~1.4x the MFMA rate of 64x64); the pixel reduction supplies the
+    // parallelism through split-K, shrinking the tile only when even that cannot fill the chip
     int ti = I > 64 ? 2 : 1, tj = J > 64 ? 2 : 1;
-    long tiles = (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj);
-    if (tiles < g_cus && tj == 2) { tj = 1; tiles = (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); }
-    if (tiles < g_cus && ti == 2) { ti = 1; tiles = (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); }
+    const long max_splits = cdiv(M, BK * 8);
+    auto ntiles = [&]() { return (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); };
+    if (ntiles() * max_splits < g_cus && tj == 2) tj = 1;
+    if (ntiles() * max_splits < g_cus && ti == 2) ti = 1;
+    const long tiles = ntiles();
     const int tile = (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
     long splits = cdiv((long)g_cus * 3, tiles);
-    const long max_splits = cdiv(M, BK * 8);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long kchunk = cdiv(M, splits);

@@ -94,15 +94,14 @@ __global__ __launch_bounds__(256) void rowmean_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, int N, int C, int P,
                                                           int ctot, int coff, float* __restrict__ db) {
     __shared__ float part[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
-    const long total = (long)N * P;
-    for (long i = threadIdx.x; i < total; i += 256) {
-        const int n = (int)(i / P), pp = (int)(i - (long)n * P);
-        s += t[((size_t)n * ctot + coff + c) * P + pp];
+    for (int n = wave; n < N; n += 4) {          // one wave walks whole (n, c) planes: contiguous, no div
+        const float* tp = t + ((size_t)n * ctot + coff + c) * P;
+        for (int i = lane; i < P; i += 64) s += tp[i];
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if (lane == 0) part[wave] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&db[c], part[0] + part[1] + part[2] + part[3]);
 }

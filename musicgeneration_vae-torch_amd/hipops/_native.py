@@ -32,6 +32,8 @@ SIGNATURES = {
     "mgvae_device_info": (c_int, [ctypes.c_char_p, c_size_t, ctypes.POINTER(c_int)]),
     "mgvae_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_conv2d_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "mgvae_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "mgvae_conv2d_bwd_data_tw": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_conv2d_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),

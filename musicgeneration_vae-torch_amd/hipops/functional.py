@@ -82,6 +82,7 @@ def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
     return nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], x_ctot, 0, y_ctot, 0, act, slope)
 
 
+USE_TRANSPOSED_W = True   # data-gradient / transposed-conv kernels read a [Cy][KK][Cx] copy of the weight
 USE_DIRECT = False  # direct (halo-tile, packed-weight) conv kernels; False = implicit-GEMM fallback only
 
 
@@ -105,6 +106,10 @@ def _conv_bwd_data(d, y, w, b, x):
         wp = torch.empty((n,), device=w.device, dtype=torch.float32)
         nat.check(L.mgvae_conv_pack(ctypes.byref(d), 1, _p(w), _p(wp), _s()), "conv_pack")
         nat.check(L.mgvae_conv2d_bwd_data_packed(ctypes.byref(d), _p(y), _p(wp), _p(b), _p(x), _s()), "conv2d_bwd_data_packed")
+    elif d.KH * d.KW > 1 and USE_TRANSPOSED_W:
+        wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+        nat.check(L.mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
+        nat.check(L.mgvae_conv2d_bwd_data_tw(ctypes.byref(d), _p(y), _p(wt), _p(b), _p(x), _s()), "conv2d_bwd_data_tw")
     else:
         nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d), _p(y), _p(w), _p(b), _p(x), _s()), "conv2d_bwd_data")
 
