@@ -74,14 +74,35 @@ class FlatParams:
                                             self.numel, vp(self._hyper), self.eps, grad_scale, s), "adam_step")
 
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.param_groups[0]["lr"], "exp_avg": self.exp_avg.clone(),
-                "exp_avg_sq": self.exp_avg_sq.clone()}
+        """torch.optim.Adam's state_dict layout (per-parameter step / exp_avg / exp_avg_sq), so the
+        reference's checkpoints (agent/barGen2.py:168-177) and this build's are interchangeable"""
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                 "amsgrad": False, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.param_groups[0]["lr"] = float(sd["lr"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        g = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = float(g["lr"])
+        self.betas, self.eps = tuple(g.get("betas", self.betas)), float(g.get("eps", self.eps))
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        steps = []
+        for i, st in sd["state"].items():
+            i = int(i)
+            if i >= len(self.params):
+                continue                      # e.g. refiner parameters of a reference checkpoint
+            p, o = self.params[i], self.offsets[i]
+            n = p.numel()
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.append(int(float(st["step"])))
+        self.step_count = max(steps) if steps else 0
 
     def buckets(self, nbuckets):
         """contiguous [start, end) slices of the flat gradient, in REVERSE parameter order
