@@ -107,6 +107,17 @@ int mgvae_instance_norm_bwd(const float* x, const float* gamma, const float* bet
                             int N, int C, int P, int dy_ctot, int dy_coff, int act, float slope,
                             void* stream);
 
+/* ---- BatchNorm2d (graph/bar_discriminator.py:19-23,69,113-114,153; graph/refiner.py) ----------
+ * training != 0: batch statistics, running_mean/var updated in place with `momentum` (unbiased
+ * variance, like torch); stats[2C] = (mean, rstd) saved.  x, y, dy, dx dense [N,C,P];
+ * dgamma / dbeta accumulate.                                                                     */
+int mgvae_batch_norm_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* y, float* stats, int N, int C, int P, int training,
+                         float momentum, float eps, int act, float slope, void* stream);
+int mgvae_batch_norm_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
+                         const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C, int P,
+                         int training, int act, float slope, void* stream);
+
 /* ---- CBAM (graph/cbam.py:22-29,43-52,63-67) fused with the residual that follows it
  * mode 0: y = cbam(u)                      (graph/cbam.py CBAM.forward)
  * mode 1: y = act(u + cbam(u))             (graph/encodingBlock.py:32,63,122; decoder.py:32,62,103,140,150,213)
@@ -140,6 +151,10 @@ int mgvae_add_inplace(float* dst, const float* src, size_t n, void* stream);
  * graph/phrase_encoder.py:21,36; bwd: dx[r, l] = dout[r] / L                          */
 int mgvae_rowmean_fwd(const float* x, float* out, int rows, int L, void* stream);
 int mgvae_rowmean_bwd(const float* dout, float* dx, int rows, int L, void* stream);
+/* out[r, g] = sum_{i<gsize} x[r, g*gsize + i]: the pitch-axis folding of the BarDiscriminator
+ * front-ends (graph/bar_discriminator.py:32-34: 60 -> 12 groups of 5; :86-87: sum over 60)      */
+int mgvae_group_sum_fwd(const float* x, float* out, size_t rows, int groups, int gsize, void* stream);
+int mgvae_group_sum_bwd(const float* dout, float* dx, size_t rows, int groups, int gsize, void* stream);
 /* nn.Embedding gather (graph/decoder.py:187,193) into a row-sliced destination and its
  * scatter-add gradient                                                                */
 int mgvae_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int D, int rows,

@@ -106,6 +106,118 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) atomicAdd(&db[c], part[0] + part[1] + part[2] + part[3]);
 }
 
+// ------------------------------------------------------------------------ BatchNorm2d
+// (BarDiscriminator / Refiner only: C <= 64 channels, launch-bound).  One workgroup per channel
+// reduces over (N, P); training mode also updates the running statistics like torch does
+// (momentum, unbiased variance) and saves (mean, rstd) for backward.
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void batch_norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ rmean,
+                                                             float* __restrict__ rvar, float* __restrict__ y,
+                                                             float* __restrict__ stats, int N, int C, int P, int training,
+                                                             float momentum, float eps, int act, float slope) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float cnt = (float)N * (float)P;
+    float mean, var;
+    if (training) {
+        float s = 0.f;
+        for (int n = wave; n < N; n += 4) {
+            const float* xp = x + ((size_t)n * C + c) * P;
+            for (int i = lane; i < P; i += 64) s += xp[i];
+        }
+        mean = block_sum(s, sh) / cnt;
+        float v = 0.f;
+        for (int n = wave; n < N; n += 4) {
+            const float* xp = x + ((size_t)n * C + c) * P;
+            for (int i = lane; i < P; i += 64) { const float d = xp[i] - mean; v += d * d; }
+        }
+        var = block_sum(v, sh) / cnt;
+        if (threadIdx.x == 0) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (cnt > 1.f ? var * cnt / (cnt - 1.f) : var);
+        }
+    } else {
+        mean = rmean[c]; var = rvar[c];
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0) { stats[2 * c] = mean; stats[2 * c + 1] = rstd; }
+    const float g = gamma[c], b = beta[c];
+    for (int n = wave; n < N; n += 4) {
+        const float* xp = x + ((size_t)n * C + c) * P;
+        float* yp = y + ((size_t)n * C + c) * P;
+        for (int i = lane; i < P; i += 64) yp[i] = apply_act((xp[i] - mean) * rstd * g + b, act, slope);
+    }
+}
+
+__global__ __launch_bounds__(256) void batch_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ stats,
+                                                             const float* __restrict__ dy, float* __restrict__ dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                             int C, int P, int training, int act, float slope) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float cnt = (float)N * (float)P;
+    const float mean = stats[2 * c], rstd = stats[2 * c + 1], g = gamma[c], b = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = wave; n < N; n += 4) {
+        const float* xp = x + ((size_t)n * C + c) * P;
+        const float* dp = dy + ((size_t)n * C + c) * P;
+        for (int i = lane; i < P; i += 64) {
+            const float xh = (xp[i] - mean) * rstd;
+            float gr = dp[i];
+            if (act != MGVAE_ACT_NONE) gr *= (xh * g + b > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
+            s1 += gr; s2 += gr * xh;
+        }
+    }
+    s1 = block_sum(s1, sh); s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] += s2;
+        if (dbeta) dbeta[c] += s1;
+    }
+    const float m1 = training ? s1 / cnt : 0.f, m2 = training ? s2 / cnt : 0.f, k = g * rstd;
+    for (int n = wave; n < N; n += 4) {
+        const float* xp = x + ((size_t)n * C + c) * P;
+        const float* dp = dy + ((size_t)n * C + c) * P;
+        float* dxp = dx + ((size_t)n * C + c) * P;
+        for (int i = lane; i < P; i += 64) {
+            const float xh = (xp[i] - mean) * rstd;
+            float gr = dp[i];
+            if (act != MGVAE_ACT_NONE) gr *= (xh * g + b > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
+            dxp[i] = k * (gr - m1 - xh * m2);
+        }
+    }
+}
+
+extern "C" int mgvae_batch_norm_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float* y, float* stats, int N, int C, int P, int training,
+                                    float momentum, float eps, int act, float slope, void* stream) {
+    if (!x || !gamma || !beta || !running_mean || !running_var || !y || !stats || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
+    if (act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(batch_norm_fwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), x, gamma, beta, running_mean,
+                       running_var, y, stats, N, C, P, training, momentum, eps, act, slope);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+extern "C" int mgvae_batch_norm_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
+                                    const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C, int P,
+                                    int training, int act, float slope, void* stream) {
+    if (!x || !gamma || !beta || !stats || !dy || !dx || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
+    if (act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(batch_norm_bwd_kernel, dim3(C), dim3(256), 0, as_stream(stream), x, gamma, beta, stats, dy, dx,
+                       dgamma, dbeta, N, C, P, training, act, slope);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
 extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                                        float* stats, int N, int C, int P, int y_ctot, int y_coff, float eps,
                                        int act, float slope, void* stream) {

@@ -78,6 +78,39 @@ extern "C" int mgvae_mul(const float* a, const float* b, float* out, size_t n, v
     return MGVAE_OK;
 }
 
+// ------------------------------------------------------------------ grouped sums over the pitch axis
+// out[r, g] = sum_{i < gsize} x[r, g*gsize + i]  (BarDiscriminator feature front-ends:
+// graph/bar_discriminator.py:32-34 chord folding 60 -> 12 x 5, :86-87 on/off sum over 60 pitches)
+__global__ __launch_bounds__(256) void group_sum_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            long rows, int groups, int gsize) {
+    const long total = rows * groups;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float* xp = x + i * gsize;      // (r*groups + g) * gsize == r*W + g*gsize
+        float s = 0.f;
+        for (int k = 0; k < gsize; ++k) s += xp[k];
+        out[i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void group_sum_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
+                                                            long total, int gsize) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) dx[i] = dout[i / gsize];
+}
+
+extern "C" int mgvae_group_sum_fwd(const float* x, float* out, size_t rows, int groups, int gsize, void* stream) {
+    if (!x || !out || rows == 0 || groups <= 0 || gsize <= 0) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(group_sum_fwd_kernel, dim3(grid_for(rows * groups)), dim3(256), 0, as_stream(stream), x, out,
+                       (long)rows, groups, gsize);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+extern "C" int mgvae_group_sum_bwd(const float* dout, float* dx, size_t rows, int groups, int gsize, void* stream) {
+    if (!dout || !dx || rows == 0 || groups <= 0 || gsize <= 0) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(group_sum_bwd_kernel, dim3(grid_for(rows * groups * gsize)), dim3(256), 0, as_stream(stream), dout, dx,
+                       (long)(rows * groups * gsize), gsize);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
 // ------------------------------------------------------------------ embedding
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
                                                             float* __restrict__ out, int B, int D, int rows, size_t pitch) {

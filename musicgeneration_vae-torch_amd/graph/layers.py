@@ -84,3 +84,23 @@ class Embedding(nn.Module):
 
     def forward(self, idx, out=None):
         return HF.embedding(idx, self.weight, out)
+
+
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d state (weight, bias, running_mean, running_var, num_batches_tracked) and
+    semantics; the class name matters: the reference's weights_init matches 'BatchNorm'."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01):
+        if self.training:
+            self.num_batches_tracked += 1
+        return HF.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                             self.momentum, self.eps, act, slope)

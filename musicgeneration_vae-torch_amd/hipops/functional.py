@@ -267,6 +267,99 @@ def instance_norm(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.01, out=None):
     return _InstNormFn.apply(x, gamma, beta, eps, act, slope, out)
 
 
+class _BatchNormFn(torch.autograd.Function):
+    """nn.BatchNorm2d (+ fused ReLU) with torch's training / eval semantics and running statistics
+    (graph/bar_discriminator.py:19-23,69,113-114,153)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, training, momentum, eps, act, slope):
+        _need_cuda(x, "batch_norm")
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((2 * C,), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_batch_norm_fwd(_p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(y), _p(stats), N, C, H * W,
+                                                 1 if training else 0, momentum, eps, act, slope, _s()), "batch_norm_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (training, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        training, act, slope = ctx.cfg
+        N, C, H, W = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = grad_slot(gamma) if gamma.requires_grad else None
+        db = grad_slot(beta) if beta.requires_grad else None
+        nat.check(nat.lib().mgvae_batch_norm_bwd(_p(x), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dx), _p(dg), _p(db), N, C,
+                                                 H * W, 1 if training else 0, act, slope, _s()), "batch_norm_bwd")
+        return (dx,) + (None,) * 9
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.01):
+    return _BatchNormFn.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, slope)
+
+
+class _GroupSumFn(torch.autograd.Function):
+    """sum over groups of `gsize` adjacent entries of the last axis (W = groups * gsize)"""
+
+    @staticmethod
+    def forward(ctx, x, gsize):
+        _need_cuda(x, "group_sum")
+        x = x.contiguous()
+        W = x.shape[-1]
+        if W % gsize:
+            raise RuntimeError("group_sum: last axis %d is not a multiple of %d" % (W, gsize))
+        groups, rows = W // gsize, x.numel() // W
+        out = torch.empty(tuple(x.shape[:-1]) + (groups,), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_group_sum_fwd(_p(x), _p(out), rows, groups, gsize, _s()), "group_sum_fwd")
+        ctx.cfg = (tuple(x.shape), rows, groups, gsize)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, rows, groups, gsize = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty(shape, device=dout.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_group_sum_bwd(_p(dout), _p(dx), rows, groups, gsize, _s()), "group_sum_bwd")
+        return dx, None
+
+
+def group_sum(x, gsize):
+    return _GroupSumFn.apply(x, gsize)
+
+
+class _CatTimeFn(torch.autograd.Function):
+    """torch.cat((a, b), dim=2) for single-channel rolls [B,1,Ha,W] + [B,1,Hb,W] (the 2-bar pairs
+    the bar discriminator sees: agent/barGen_with_gan.py:487-490)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_cuda(a, "cat_time")
+        a, b = a.contiguous(), b.contiguous()
+        B, C, Ha, W = a.shape
+        Hb = b.shape[2]
+        if C != 1 or b.shape[1] != 1:
+            raise RuntimeError("cat_time handles single-channel piano rolls")
+        out = torch.empty((B, 1, Ha + Hb, W), device=a.device, dtype=torch.float32)
+        L = nat.lib()
+        pitch = (Ha + Hb) * W
+        nat.check(L.mgvae_copy2d(_p(out), pitch, _p(a), Ha * W, Ha * W, B, _s()), "cat_time")
+        nat.check(L.mgvae_copy2d(_vp(out.data_ptr() + 4 * Ha * W), pitch, _p(b), Hb * W, Hb * W, B, _s()), "cat_time")
+        ctx.ha = Ha
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[:, :, :ctx.ha], d[:, :, ctx.ha:]
+
+
+def cat_time(a, b):
+    return _CatTimeFn.apply(a, b)
+
+
 # ================================================================================ CBAM
 class _CbamFn(torch.autograd.Function):
     """graph/cbam.py CBAM.forward fused with the residual/activation that follows it."""

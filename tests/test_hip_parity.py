@@ -497,3 +497,86 @@ def test_train_step_against_oracle_and_golden(golden_dir):
         mm = 0.1 * g; vv = 0.001 * g * g
         want = p0 - (0.002 / 0.1) * mm / (vv.sqrt() / (0.001 ** 0.5) + 1e-8)
         check("adam " + n, params[n].detach().double().cpu() - p0, want - p0, 1e-4)
+
+
+# ------------------------------------------------------------------------- discriminators
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act", [0, 1])
+def test_batch_norm(training, act):
+    x = torch.randn(5, 16, 12, 7) * 2 + 0.5
+    g = torch.randn(16); b = torch.randn(16)
+    rm, rv = torch.randn(16) * 0.1, torch.rand(16) + 0.5
+    xr, gr, br = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, training, 0.01, 1e-5)
+    yr = F.relu(yr) if act else yr
+    dy = torch.randn_like(yr); yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); gd = torch.nn.Parameter(g.to(dev)); bd = torch.nn.Parameter(b.to(dev))
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    y = HF().batch_norm(xd, gd, bd, rmd, rvd, training, 0.01, 1e-5, act)
+    tag = "batchnorm train=%s act=%d" % (training, act)
+    check(tag + " fwd", y, yr)
+    y.backward(dy.float().to(dev))
+    check(tag + " dx", xd.grad, xr.grad); check(tag + " dgamma", gd.grad, gr.grad); check(tag + " dbeta", bd.grad, br.grad)
+    check(tag + " running_mean", rmd, rmr); check(tag + " running_var", rvd, rvr)
+
+
+def test_group_sum_and_cat_time():
+    x = torch.randn(3, 1, 192, 60)
+    xr = x.double().requires_grad_(True)
+    cr = torch.sum(xr.view(-1, 1, 192, 12, 5), 4); orr = torch.sum(xr, 3, keepdim=True)
+    d1, d2 = torch.randn_like(cr), torch.randn_like(orr)
+    (cr * d1).sum().backward(retain_graph=True); g1 = xr.grad.clone(); xr.grad = None
+    (orr * d2).sum().backward(); g2 = xr.grad.clone()
+    xd = x.to(dev).requires_grad_(True)
+    c = HF().group_sum(xd, 5); check("group_sum(5) fwd", c, cr)
+    (c * d1.float().to(dev)).sum().backward(); check("group_sum(5) bwd", xd.grad, g1); xd.grad = None
+    o = HF().group_sum(xd, 60); check("group_sum(60) fwd", o, orr)
+    (o * d2.float().to(dev)).sum().backward(); check("group_sum(60) bwd", xd.grad, g2)
+    a = torch.randn(3, 1, 96, 60, device=dev, requires_grad=True); b = torch.randn(3, 1, 96, 60, device=dev, requires_grad=True)
+    ct = HF().cat_time(a, b)
+    assert torch.equal(ct, torch.cat((a, b), dim=2))
+    w = torch.randn_like(ct); (ct * w).sum().backward()
+    assert torch.equal(a.grad, w[:, :, :96]) and torch.equal(b.grad, w[:, :, 96:])
+
+
+@pytest.mark.parametrize("mode", ["wc", "d4"])
+def test_discriminators_against_oracle_and_golden(golden_dir, mode):
+    from graph.bar_discriminator import BarDiscriminator
+    from graph.z_discriminator import BarZDiscriminator
+    from graph.bar_discriminator_with_feature import BarFeatureDiscriminator
+    fx = np.load(os.path.join(golden_dir, "generator_%s.npz" % mode))
+    z = torch.from_numpy(fx["z"])
+    zsd = W.make_state_dict(W.manifest_z_discriminator(), 0, mode)
+    fsd = W.make_state_dict(W.manifest_bar_feature_discriminator(), 0, mode)
+    bsd = W.make_state_dict(W.manifest_bar_discriminator(), 0, mode)
+    zb = BarZDiscriminator(); zb.load_state_dict(zsd); zb = zb.to(dev)
+    fd = BarFeatureDiscriminator(); fd.load_state_dict(fsd); fd = fd.to(dev)
+    check("BarZDiscriminator[%s] vs golden" % mode, zb(z.to(dev)), torch.from_numpy(fx["d_zbar"]))
+    check("BarFeatureDiscriminator[%s] vs golden" % mode, fd(z.to(dev)), torch.from_numpy(fx["d_feature"]))
+    # bar discriminator: forward vs golden (reference import), gradients vs the fp64 oracle
+    note, pre, _, _ = W.make_inputs(4, seed=1234)
+    pair = torch.cat((pre, note), dim=2)
+    bd = BarDiscriminator(); bd.load_state_dict(bsd); bd = bd.to(dev).train()
+    pd_ = pair.to(dev).requires_grad_(True)
+    out = bd(pd_)
+    tol = TOL if mode == "wc" else 5e-3
+    check("BarDiscriminator[%s] fwd vs golden" % mode, out, torch.from_numpy(fx["d_bar"]), tol)
+    run = torch.cat([v.detach().flatten().cpu() for k, v in bd.state_dict().items() if "running" in k])
+    check("BarDiscriminator[%s] running stats vs golden" % mode, run, torch.from_numpy(fx["bd_running"]), tol)
+    osd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else
+               (v.clone().double() if v.is_floating_point() else v.clone())) for k, v in bsd.items()}
+    pr = pair.double().requires_grad_(True)
+    o = R.bar_discriminator(osd, "", pr, train=True)
+    dy = torch.randn_like(o); o.backward(dy)
+    o32sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in bsd.items()}
+    p32 = pair.clone().requires_grad_(True)
+    R.bar_discriminator(o32sd, "", p32, train=True).backward(dy.float())
+    out.backward(dy.float().to(dev))
+    gscale = max(v.grad.abs().max().item() for v in osd.values() if getattr(v, "grad", None) is not None)
+    check_grad("BarDiscriminator[%s] dx" % mode, pd_.grad, pr.grad, tol, ref32=p32.grad)
+    for n, p in bd.named_parameters():
+        if osd[n].grad is None:      # basic.layers.2.bn1.* is constructed but never used (isBasic=True)
+            assert p.grad is None or p.grad.abs().max().item() == 0, n
+            continue
+        check_grad("BarDiscriminator[%s] d%s" % (mode, n), p.grad, osd[n].grad, tol, atol=1e-6 * gscale, ref32=o32sd[n].grad)
