@@ -104,6 +104,20 @@ class FlatParams:
             steps.append(int(float(st["step"])))
         self.step_count = max(steps) if steps else 0
 
+    def second_state(self, lr=None):
+        """another Adam over the SAME parameters and gradients with its own moments and step
+        count (the reference's agent/barGen.py:60-62 builds opt_gen1 / opt_gen2 this way)"""
+        o = object.__new__(FlatParams)
+        o.params, o.offsets, o.numel = self.params, self.offsets, self.numel
+        o.flat, o.grad = self.flat, self.grad
+        o.exp_avg, o.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        o.lr, o.betas, o.eps = (lr if lr is not None else self.lr), self.betas, self.eps
+        o.step_count = 0
+        o._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        o._hyper = torch.zeros(4, device=self.flat.device, dtype=torch.float32)
+        o.param_groups = [{"lr": o.lr, "params": o.params}]
+        return o
+
     def buckets(self, nbuckets):
         """contiguous [start, end) slices of the flat gradient, in REVERSE parameter order
         (gradients of the last layers are ready first in backward)"""
