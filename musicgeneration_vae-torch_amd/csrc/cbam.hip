@@ -58,32 +58,40 @@ __global__ __launch_bounds__(256) void cbam_chan_pool_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- F2: shared MLP + sigmoid
-// one workgroup per sample; dynamic LDS: avg[C], max[C], ha[Cr], hm[Cr]
-__global__ __launch_bounds__(256) void cbam_chan_mlp_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
-                                                            const float* __restrict__ w1, const float* __restrict__ w2,
-                                                            float* __restrict__ hid, float* __restrict__ cg, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int Cr = C / 16, n = blockIdx.x, tid = threadIdx.x;
-    float* sa = sm; float* sx = sm + C; float* ha = sm + 2 * C; float* hm = ha + Cr;
-    for (int c = tid; c < C; c += 256) { sa[c] = avg[(size_t)n * C + c]; sx[c] = mx[(size_t)n * C + c]; }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < Cr; j += 4) {
-        float a = 0.f, m = 0.f;
-        for (int c = lane; c < C; c += 64) { const float w = w1[(size_t)j * C + c]; a += w * sa[c]; m += w * sx[c]; }
-        a = wave_sum(a); m = wave_sum(m);
-        if (lane == 0) {
-            a = a > 0.f ? a : 0.f; m = m > 0.f ? m : 0.f;
-            ha[j] = a; hm[j] = m;
-            hid[(size_t)n * 2 * Cr + j] = a; hid[(size_t)n * 2 * Cr + Cr + j] = m;
-        }
+// F2a: hidden[n, {avg,max}, j] = relu(W1[j,:] . pool[n,:]) -- one wave per (n, j), so the launch has
+// N*Cr waves instead of N latency-bound workgroups.  F2b: gate[n,c], one thread per (n, c).
+__global__ __launch_bounds__(256) void cbam_chan_hidden_kernel(const float* __restrict__ avg, const float* __restrict__ mx,
+                                                               const float* __restrict__ w1, float* __restrict__ hid,
+                                                               int N, int C) {
+    const int Cr = C / 16;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + wave;
+    if (id >= N * Cr) return;
+    const int n = id / Cr, j = id - n * Cr;
+    const float* wr = w1 + (size_t)j * C;
+    const float* ap = avg + (size_t)n * C;
+    const float* mp = mx + (size_t)n * C;
+    float a = 0.f, m = 0.f;
+    for (int c = lane; c < C; c += 64) { const float w = wr[c]; a += w * ap[c]; m += w * mp[c]; }
+    a = wave_sum(a); m = wave_sum(m);
+    if (lane == 0) {
+        hid[(size_t)n * 2 * Cr + j] = a > 0.f ? a : 0.f;
+        hid[(size_t)n * 2 * Cr + Cr + j] = m > 0.f ? m : 0.f;
     }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float a = 0.f, m = 0.f;
-        for (int j = 0; j < Cr; ++j) { const float w = w2[(size_t)c * Cr + j]; a += w * ha[j]; m += w * hm[j]; }
-        cg[(size_t)n * C + c] = 1.f / (1.f + expf(-(a + m)));
-    }
+}
+
+__global__ __launch_bounds__(256) void cbam_chan_gate_kernel(const float* __restrict__ hid, const float* __restrict__ w2,
+                                                             float* __restrict__ cg, int N, int C) {
+    const int Cr = C / 16;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= N * C) return;
+    const int n = id / C, c = id - n * C;
+    const float* ha = hid + (size_t)n * 2 * Cr;
+    const float* hm = ha + Cr;
+    const float* wr = w2 + (size_t)c * Cr;
+    float a = 0.f, m = 0.f;
+    for (int j = 0; j < Cr; ++j) { const float w = wr[j]; a += w * ha[j]; m += w * hm[j]; }
+    cg[id] = 1.f / (1.f + expf(-(a + m)));
 }
 
 // ---------------------------------------------------------------- F3: spatial pooling
@@ -301,43 +309,41 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_kernel(
     if (lane == 0) dcg[nc] = acc;
 }
 
-// B4a: MLP backward per sample (no weight gradients here).  dynamic LDS: dpre[C], ha,hm,dha,dhm[Cr]
-// writes dpre[N,C] (over dcg), dh[N,2,Cr], davg[N,C], dmaxp[N,C]
-__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(float* __restrict__ dcg, const float* __restrict__ cg,
-                                                           const float* __restrict__ hid, const float* __restrict__ w1,
-                                                           const float* __restrict__ w2, float* __restrict__ dh,
-                                                           float* __restrict__ davg, float* __restrict__ dmaxp, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int Cr = C / 16, n = blockIdx.x, tid = threadIdx.x;
-    float* dpre = sm; float* ha = sm + C; float* hm = ha + Cr; float* dha = hm + Cr; float* dhm = dha + Cr;
-    for (int c = tid; c < C; c += 256) {
-        const float g = cg[(size_t)n * C + c];
-        const float v = dcg[(size_t)n * C + c] * g * (1.f - g);
-        dpre[c] = v;
-        dcg[(size_t)n * C + c] = v;           // dcg now holds dpre for the weight-gradient kernel
+// B4a: MLP backward, fully parallel: (1) dpre[n,c] = dcg * cg * (1 - cg) in place; (2) one wave per
+// (n, j): dh = W2[:,j] . dpre[n,:], masked by the two ReLUs; (3) one thread per (n, c): davg / dmaxp.
+__global__ __launch_bounds__(256) void cbam_bwd_dpre_kernel(float* __restrict__ dcg, const float* __restrict__ cg, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) { const float g = cg[i]; dcg[i] = dcg[i] * g * (1.f - g); }
+}
+
+__global__ __launch_bounds__(256) void cbam_bwd_dh_kernel(const float* __restrict__ dpre, const float* __restrict__ hid,
+                                                          const float* __restrict__ w2, float* __restrict__ dh, int N, int C) {
+    const int Cr = C / 16;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + wave;
+    if (id >= N * Cr) return;
+    const int n = id / Cr, j = id - n * Cr;
+    const float* dp = dpre + (size_t)n * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w2[(size_t)c * Cr + j] * dp[c];
+    s = wave_sum(s);
+    if (lane == 0) {
+        dh[(size_t)n * 2 * Cr + j] = hid[(size_t)n * 2 * Cr + j] > 0.f ? s : 0.f;
+        dh[(size_t)n * 2 * Cr + Cr + j] = hid[(size_t)n * 2 * Cr + Cr + j] > 0.f ? s : 0.f;
     }
-    for (int j = tid; j < Cr; j += 256) { ha[j] = hid[(size_t)n * 2 * Cr + j]; hm[j] = hid[(size_t)n * 2 * Cr + Cr + j]; }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < Cr; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += w2[(size_t)c * Cr + j] * dpre[c];
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float a = ha[j] > 0.f ? s : 0.f, m = hm[j] > 0.f ? s : 0.f;
-            dha[j] = a; dhm[j] = m;
-            dh[(size_t)n * 2 * Cr + j] = a; dh[(size_t)n * 2 * Cr + Cr + j] = m;
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float da = 0.f, dm = 0.f;
-        for (int j = 0; j < Cr; ++j) {
-            const float w = w1[(size_t)j * C + c];
-            da += w * dha[j]; dm += w * dhm[j];
-        }
-        davg[(size_t)n * C + c] = da; dmaxp[(size_t)n * C + c] = dm;
-    }
+}
+
+__global__ __launch_bounds__(256) void cbam_bwd_dpool_kernel(const float* __restrict__ dh, const float* __restrict__ w1,
+                                                             float* __restrict__ davg, float* __restrict__ dmaxp, int N, int C) {
+    const int Cr = C / 16;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= N * C) return;
+    const int n = id / C, c = id - n * C;
+    const float* da = dh + (size_t)n * 2 * Cr;
+    const float* dm = da + Cr;
+    float a = 0.f, m = 0.f;
+    for (int j = 0; j < Cr; ++j) { const float w = w1[(size_t)j * C + c]; a += w * da[j]; m += w * dm[j]; }
+    davg[id] = a; dmaxp[id] = m;
 }
 
 // B4b: weight gradients as a batched reduction over the samples; one thread owns one (c, j)
@@ -400,8 +406,8 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
     const int P = H * W, NC = N * C, Cr = C / 16;
     CbamSave sv = carve(save, N, C, P);
     hipLaunchKernelGGL(cbam_chan_pool_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, sv.avg, sv.mx, sv.amax_hw, NC, P);
-    hipLaunchKernelGGL(cbam_chan_mlp_kernel, dim3(N), dim3(256), (2 * C + 2 * Cr) * sizeof(float), s, sv.avg, sv.mx,
-                       w1, w2, sv.hid, sv.cg, C);
+    hipLaunchKernelGGL(cbam_chan_hidden_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, sv.avg, sv.mx, w1, sv.hid, N, C);
+    hipLaunchKernelGGL(cbam_chan_gate_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, sv.hid, w2, sv.cg, N, C);
     switch (pick_pxb((long)N * P)) {
         case 64: hipLaunchKernelGGL(cbam_spatial_pool_kernel<64>, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
         case 32: hipLaunchKernelGGL(cbam_spatial_pool_kernel<32>, dim3(cdiv((long)N * P, 32)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
@@ -443,8 +449,9 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
                        dwsp, N, H, W);
     hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
                        sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
-    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(N), dim3(256), (C + 4 * Cr) * sizeof(float), s, dcg, sv.cg, sv.hid,
-                       w1, w2, dh, davg, dmaxp, C);
+    hipLaunchKernelGGL(cbam_bwd_dpre_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dcg, sv.cg, NC);
+    hipLaunchKernelGGL(cbam_bwd_dh_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, dcg, sv.hid, w2, dh, N, C);
+    hipLaunchKernelGGL(cbam_bwd_dpool_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dh, w1, davg, dmaxp, N, C);
     if (dw1 || dw2)
         hipLaunchKernelGGL(cbam_bwd_mlp_wgrad_kernel, dim3(cdiv((long)C * Cr, 256)), dim3(256), 0, s, dcg, sv.hid, dh, sv.avg,
                            sv.mx, dw1, dw2, N, C);

@@ -14,6 +14,7 @@
 // conflict-free.
 #include "mgvae_common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -47,23 +48,23 @@ enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
 // ---------------------------------------------------------------------------------------
 // MFMA over one staged K-tile.  A image: A_IK ? As[i][LDP] : As[k][IT];
 //                               B image: B_KJ ? Bs[k][JT]  : Bs[j][LDP].
-template <int TI, int TJ, bool A_IK, bool B_KJ>
+template <int TI, int TJ, bool A_IK, bool B_KJ, int BKc>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                          f32x16 (&acc)[TI][TJ], int wi, int wj, int l31, int h) {
-    constexpr int IT = 64 * TI, JT = 64 * TJ;
+    constexpr int IT = 64 * TI, JT = 64 * TJ, LDPc = BKc + 1;
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = 0; kk < BKc / 2; ++kk) {
         const int k = 2 * kk + h;
         float a[TI], b[TJ];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
             const int i = wi * 32 * TI + ti * 32 + l31;
-            a[ti] = A_IK ? As[i * LDP + k] : As[k * IT + i];
+            a[ti] = A_IK ? As[i * LDPc + k] : As[k * IT + i];
         }
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) {
             const int j = wj * 32 * TJ + tj * 32 + l31;
-            b[tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDP + k];
+            b[tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDPc + k];
         }
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -89,9 +90,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     constexpr int IT = 64 * TI, JT = 64 * TJ;
     constexpr bool A_IK = (MODE != MODE_BWD_DATA);   // weights [cy][k] / dY [cy][pix]: k contiguous
     constexpr bool B_KJ = (MODE != MODE_BWD_WEIGHT); // gathers with pixels along lanes
-    constexpr int A_ELEMS = A_IK ? IT * LDP : BK * IT;
-    constexpr int B_ELEMS = B_KJ ? BK * JT : JT * LDP;
-    constexpr int NA = IT * BK / 256, NB = JT * BK / 256;
+    // K tile: 16 for the 128x128 tile (LDS), 32 for the narrower tiles (half the barriers per MFMA)
+    constexpr int BKc = (TI * TJ == 4) ? 16 : 32;
+    constexpr int LDPc = BKc + 1;          // padded row length of the "row-major, k fastest" LDS images
+    constexpr int RP = 256 / BKc;          // rows per pass of the "lanes along k" loaders
+    constexpr int A_ELEMS = A_IK ? IT * LDPc : BKc * IT;
+    constexpr int B_ELEMS = B_KJ ? BKc * JT : JT * LDPc;
+    constexpr int NA = IT * BKc / 256, NB = JT * BKc / 256;
 
     __shared__ float lds[2 * (A_ELEMS + B_ELEMS)];
     float* As0 = lds;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     if constexpr (MODE == MODE_FWD) {
         Itot = p.Cy; Jtot = p.N * P; T = p.KH * p.KW; Ktot = p.Cx * T;
         split = blockIdx.z;
-        const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+        const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BKc - 1) / BKc * BKc;
         kbeg = split * kc; kend = min(Ktot, kbeg + kc);
     } else if constexpr (MODE == MODE_BWD_DATA) {
         const int ph = blockIdx.z / p.ksplit;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         Pp = Ha * Wb;
         Itot = p.Cx; Jtot = p.N * Pp; T = nkh * nkw; Ktot = p.Cy * T;
         {
-            const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BK - 1) / BK * BK;
+            const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BKc - 1) / BKc * BKc;
             kbeg = split * kc; kend = min(Ktot, kbeg + kc);
             if (split > 0 && kbeg >= Ktot) return;   // nothing left for this split (split 0 still writes bias)
         }
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     const int jc = wave % JC, jkr0 = (wave / JC) * NB;
     const int ic = wave % IC, ikr0 = (wave / IC) * NA;
     // "lanes along k" mapping (IK / JK images): 16 lanes per row, 16 rows per pass.
-    const int kl = tid & 15, rr = tid >> 4;
+    const int kl = tid % BKc, rr = tid / BKc;
 
     // B gather state (FWD: from X; BWD_DATA: from Y)
     bool bj_valid = false; int b_pix = 0, b_r0 = 0, b_c0 = 0, b_RH = 1, b_RW = 1;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         w_n = kp / P; w_p = kp - w_n * P;
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-            const int gj = j0 + rr + 16 * r;
+            const int gj = j0 + rr + RP * r;
             if (gj < Jtot) {
                 const int KK = p.KH * p.KW;
                 const int cx = gj / KK, t = gj - cx * KK;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             const bool kok = gk < kend;
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
-                const int gi = i0 + rr + 16 * r;
+                const int gi = i0 + rr + RP * r;
                 const bool ok = kok && gi < Itot;
                 const float v = p.Wt[ok ? (size_t)gi * Ktot + gk : 0];
                 ra[r] = ok ? v : 0.f;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             const int base = (w_n * p.y_ctot + p.y_coff) * P + w_p;
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
-                const int gi = i0 + rr + 16 * r;
+                const int gi = i0 + rr + RP * r;
                 const bool ok = kok && gi < Itot;
                 const float v = p.Y[ok ? base + gi * P : 0];
                 ra[r] = ok ? v : 0.f;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
                 rb[r] = ok ? v : 0.f;
             }
             // advance this thread's pixel by one K tile
-            w_p += BK;
+            w_p += BKc;
             while (w_p >= P) { w_p -= P; ++w_n; }
         }
     };
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         float* Bs = Bs0 + buf * B_ELEMS;
         if constexpr (A_IK) {
 #pragma unroll
-            for (int r = 0; r < NA; ++r) As[(rr + 16 * r) * LDP + kl] = ra[r];
+            for (int r = 0; r < NA; ++r) As[(rr + RP * r) * LDPc + kl] = ra[r];
         } else {
 #pragma unroll
             for (int r = 0; r < NA; ++r) As[(ikr0 + r) * IT + ic * 64 + lane] = ra[r];
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             for (int r = 0; r < NB; ++r) Bs[(jkr0 + r) * JT + jc * 64 + lane] = rb[r];
         } else {
 #pragma unroll
-            for (int r = 0; r < NB; ++r) Bs[(rr + 16 * r) * LDP + kl] = rb[r];
+            for (int r = 0; r < NB; ++r) Bs[(rr + RP * r) * LDPc + kl] = rb[r];
         }
     };
 
@@ -307,15 +312,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
-    const int nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+    const int nt = kend > kbeg ? (kend - kbeg + BKc - 1) / BKc : 0;
     if (nt > 0) {
         load_tile(kbeg);
         store_tile(0);
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
-            if (t + 1 < nt) load_tile(kbeg + (t + 1) * BK);
-            mma_tile<TI, TJ, A_IK, B_KJ>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, wi, wj, l31, h);
+            if (t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
+            mma_tile<TI, TJ, A_IK, B_KJ, BKc>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, wi, wj, l31, h);
             if (t + 1 < nt) store_tile(buf ^ 1);
             __syncthreads();
         }
@@ -445,7 +450,7 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
         int str = 0;
         const int KK = d->KH * d->KW;
         if (mode == MODE_FWD) {
-            str = d->Cx * KK + 16;
+            str = d->Cx * KK + 32;
             host.assign(str, make_int2(0, 0));
             for (int c = 0; c < d->Cx; ++c)
                 for (int t = 0; t < KK; ++t) {
@@ -462,7 +467,7 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
                 const int nkw = kw0 < d->KW ? (d->KW - kw0 + d->SW - 1) / d->SW : 0;
                 if (nkh * nkw > maxT) maxT = nkh * nkw;
             }
-            str = d->Cy * maxT + 16;
+            str = d->Cy * maxT + 32;
             host.assign((size_t)Z * str, make_int2(0, 0));
             whost.assign((size_t)Z * str, 0);
             for (int ph = 0; ph < Z; ++ph) {
@@ -497,11 +502,13 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
 
 // tile ids: 0 = 128x128, 1 = 64(i)x128(j), 2 = 128(i)x64(j), 3 = 64x64.
 // Under-filled launches first split K (keeps the efficient big tiles), then shrink the tile.
-static int pick_tile(long Itot, long Jtot, int Z, long Kmin, int* ksplit) {
+static int pick_tile(long Itot, long Jtot, int Z, long Kmin, int* ksplit, bool allow_split = true) {
     int ti = Itot > 64 ? 2 : 1, tj = Jtot > 64 ? 2 : 1;
     auto wgs = [&](int a, int b) { return (long)cdiv(Itot, 64 * a) * cdiv(Jtot, 64 * b) * Z; };
     const long want = (long)g_cus * 2;
-    const long maxsplit = Kmin / (BK * 8) > 1 ? Kmin / (BK * 8) : 1;
+    static const int env_nosplit = getenv("MGVAE_NOSPLIT") ? atoi(getenv("MGVAE_NOSPLIT")) : 0;
+    if (env_nosplit == 1) allow_split = false;
+    const long maxsplit = (allow_split && Kmin / (BK * 8) > 1) ? Kmin / (BK * 8) : 1;
     if (wgs(ti, tj) * maxsplit < want && tj == 2) tj = 1;
     if (wgs(ti, tj) * maxsplit < want && ti == 2) ti = 1;
     long sp = cdiv(want, wgs(ti, tj));
@@ -610,7 +617,8 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
     // smallest per-phase K: Cy * (fewest taps a phase has, at least 1)
     const long tmin = (long)(d->KH / d->SH > 0 ? d->KH / d->SH : 1) * (d->KW / d->SW > 0 ? d->KW / d->SW : 1);
     int ksplit = 1;
-    const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit);
+    static const int env_strided = getenv("MGVAE_STRIDED_NOSPLIT") ? atoi(getenv("MGVAE_STRIDED_NOSPLIT")) : 0;
+    const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit, !(env_strided && Z > 1));
     const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
     p.ksplit = ksplit;
     if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(x + (size_t)d->x_coff * d->H * d->W, d->N, d->Cx, (long)d->H * d->W, d->x_ctot, as_stream(stream)); }
@@ -679,7 +687,7 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long kchunk = cdiv(M, splits);
-    kchunk = (kchunk + BK - 1) / BK * BK;
+    kchunk = (kchunk + 31) / 32 * 32;
     splits = cdiv(M, kchunk);
     p.kchunk = (int)kchunk;
     dim3 grid(cdiv(J, 64 * tj), cdiv(I, 64 * ti), (unsigned)splits);

@@ -71,6 +71,120 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------ register-resident variants
+// P % 4 == 0 and P <= 256*NV: the whole plane lives in NV float4 registers per lane, so x (and dy)
+// are read from HBM exactly once, as 16-byte lane-contiguous loads.
+template <int NV>
+__global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ stats, int NC, int C, int P, int y_ctot, int y_coff,
+    float eps, int act, float slope) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= NC) return;
+    const int n = nc / C, c = nc - n * C;
+    const int P4 = P >> 2;
+    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)nc * P);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < P4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) / (float)P;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (lane + 64 * k < P4) {
+            const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float var = wave_sum(q) / (float)P;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
+    const float g = gamma[c], b = beta[c];
+    float4* yp = reinterpret_cast<float4*>(y + ((size_t)n * y_ctot + y_coff + c) * P);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < P4) {
+            float4 o;
+            o.x = apply_act((v[k].x - mean) * rstd * g + b, act, slope);
+            o.y = apply_act((v[k].y - mean) * rstd * g + b, act, slope);
+            o.z = apply_act((v[k].z - mean) * rstd * g + b, act, slope);
+            o.w = apply_act((v[k].w - mean) * rstd * g + b, act, slope);
+            yp[i] = o;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stats, const float* __restrict__ dy, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int C, int P, int dy_ctot, int dy_coff,
+    int act, float slope) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= NC) return;
+    const int n = nc / C, c = nc - n * C;
+    const int P4 = P >> 2;
+    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)nc * P);
+    const float4* dyp = reinterpret_cast<const float4*>(dy + ((size_t)n * dy_ctot + dy_coff + c) * P);
+    float4* dxp = reinterpret_cast<float4*>(dx + (size_t)nc * P);
+    const float mean = stats[2 * nc], rstd = stats[2 * nc + 1];
+    const float g = gamma[c], b = beta[c];
+    const float neg = act == MGVAE_ACT_LEAKY ? slope : 0.f;
+    float4 xh[NV], gr[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < P4) {
+            const float4 xv = xp[i];
+            float4 gv = dyp[i];
+            float4 h;
+            h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
+            if (act != MGVAE_ACT_NONE) {
+                gv.x *= (h.x * g + b > 0.f) ? 1.f : neg; gv.y *= (h.y * g + b > 0.f) ? 1.f : neg;
+                gv.z *= (h.z * g + b > 0.f) ? 1.f : neg; gv.w *= (h.w * g + b > 0.f) ? 1.f : neg;
+            }
+            xh[k] = h; gr[k] = gv;
+            s1 += (gv.x + gv.y) + (gv.z + gv.w);
+            s2 += (gv.x * h.x + gv.y * h.y) + (gv.z * h.z + gv.w * h.w);
+        } else {
+            xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); gr[k] = xh[k];
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        if (dgamma) atomicAdd(&dgamma[c], s2);
+        if (dbeta) atomicAdd(&dbeta[c], s1);
+    }
+    const float m1 = s1 / (float)P, m2 = s2 / (float)P, kq = g * rstd;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < P4) {
+            float4 o;
+            o.x = kq * (gr[k].x - m1 - xh[k].x * m2); o.y = kq * (gr[k].y - m1 - xh[k].y * m2);
+            o.z = kq * (gr[k].z - m1 - xh[k].z * m2); o.w = kq * (gr[k].w - m1 - xh[k].w * m2);
+            dxp[i] = o;
+        }
+    }
+}
+
+static inline int pick_nv(int P) {          // float4 slots per lane, or 0 for the generic kernel
+    if (P & 3) return 0;
+    const int need = (P / 4 + 63) / 64;
+    return need <= 1 ? 1 : need <= 2 ? 2 : need <= 6 ? 6 : need <= 23 ? 23 : 0;
+}
+
 // ------------------------------------------------------------------------ row mean
 __global__ __launch_bounds__(256) void rowmean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           int rows, int L) {
@@ -224,8 +338,19 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
     if (!x || !gamma || !beta || !y || !stats || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
     if (y_coff < 0 || y_coff + C > y_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
-    hipLaunchKernelGGL(instance_norm_fwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
-                       beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope);
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+#define MGVAE_INF(NV) hipLaunchKernelGGL(instance_norm_fwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
+                                         gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope)
+    switch (al ? pick_nv(P) : 0) {
+        case 1: MGVAE_INF(1); break;
+        case 2: MGVAE_INF(2); break;
+        case 6: MGVAE_INF(6); break;
+        case 23: MGVAE_INF(23); break;
+        default:
+            hipLaunchKernelGGL(instance_norm_fwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
+                               beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope);
+    }
+#undef MGVAE_INF
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }
@@ -236,8 +361,19 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
     if (!x || !gamma || !beta || !stats || !dy || !dx || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
     if (dy_coff < 0 || dy_coff + C > dy_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
-    hipLaunchKernelGGL(instance_norm_bwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
-                       beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope);
+    const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+#define MGVAE_INB(NV) hipLaunchKernelGGL(instance_norm_bwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
+                                         gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope)
+    switch (al ? pick_nv(P) : 0) {
+        case 1: MGVAE_INB(1); break;
+        case 2: MGVAE_INB(2); break;
+        case 6: MGVAE_INB(6); break;
+        case 23: MGVAE_INB(23); break;
+        default:
+            hipLaunchKernelGGL(instance_norm_bwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
+                               beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope);
+    }
+#undef MGVAE_INB
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }
