@@ -122,19 +122,20 @@ int mgvae_batch_norm_bwd(const float* x, const float* gamma, const float* beta, 
  * mode 0: y = cbam(u)                      (graph/cbam.py CBAM.forward)
  * mode 1: y = act(u + cbam(u))             (graph/encodingBlock.py:32,63,122; decoder.py:32,62,103,140,150,213)
  * mode 2: y = act(res + cbam(u))           (graph/encodingBlock.py:94-98)
- * u [N,C,P] contiguous, P = H*W; w1 [C/16,C], w2 [C,C/16], wsp [1,2,3,3].
+ * parts: 3 = channel then spatial attention (CBAM); 1 = ChannelAttention alone (graph/cbam.py:22-29);
+ * 2 = SpatialAttention alone (:43-52).  u [N,C,P] contiguous, P = H*W; w1 [C/16,C], w2 [C,C/16], wsp [1,2,3,3].
  * Workspace `save` (floats, size mgvae_cbam_save_floats) keeps what backward needs.   */
 size_t mgvae_cbam_save_floats(int N, int C, int H, int W);
 int mgvae_cbam_fwd(const float* u, const float* res, const float* w1, const float* w2, const float* wsp,
                    float* y, float* save, int N, int C, int H, int W, int y_ctot, int y_coff,
-                   int mode, int act, float slope, void* stream);
+                   int mode, int act, float slope, int parts, void* stream);
 /* du (contiguous) and dres (contiguous, mode 2 only) are written; dw1/dw2/dwsp accumulate.
  * y/dy are channel-sliced (ctot, coff).  `scratch` needs mgvae_cbam_bwd_scratch_floats.  */
 size_t mgvae_cbam_bwd_scratch_floats(int N, int C, int H, int W);
 int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, const float* w1, const float* w2,
                    const float* wsp, const float* save, float* du, float* dres, float* dw1, float* dw2,
                    float* dwsp, float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff,
-                   int mode, int act, float slope, void* stream);
+                   int mode, int act, float slope, int parts, void* stream);
 
 /* ---- pointwise / small ops ---------------------------------------------------------*/
 /* dx = dy * act'(y) given the activation OUTPUT y (ReLU/LeakyReLU/Sigmoid); all three

@@ -382,6 +382,14 @@ __global__ __launch_bounds__(256) void cbam_bwd_finish_kernel(float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void cbam_fill_kernel(float* __restrict__ t, float v, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) t[i] = v;
+}
+static void cbam_fill(float* t, float v, long n, hipStream_t s) {
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cbam_fill_kernel, dim3(blocks), dim3(256), 0, s, t, v, n);
+}
+
 // ================================================================ host entry points
 extern "C" size_t mgvae_cbam_save_floats(int N, int C, int H, int W) { return cbam_save_floats(N, C, H * W); }
 extern "C" size_t mgvae_cbam_bwd_scratch_floats(int N, int C, int H, int W) {
@@ -398,16 +406,23 @@ static int cbam_check(int N, int C, int H, int W, int ctot, int coff, int mode, 
 
 extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1, const float* w2, const float* wsp,
                               float* y, float* save, int N, int C, int H, int W, int y_ctot, int y_coff, int mode,
-                              int act, float slope, void* stream) {
+                              int act, float slope, int parts, void* stream) {
     int rc = cbam_check(N, C, H, W, y_ctot, y_coff, mode, act);
     if (rc) return rc;
-    if (!u || !w1 || !w2 || !wsp || !y || !save || (mode == 2 && !res)) return MGVAE_EINVAL;
+    if (parts < 1 || parts > 3) return MGVAE_EINVAL;
+    const bool chan = parts & 1, spat = parts & 2;
+    if (!u || !y || !save || (mode == 2 && !res) || (chan && (!w1 || !w2)) || (spat && !wsp)) return MGVAE_EINVAL;
     hipStream_t s = as_stream(stream);
     const int P = H * W, NC = N * C, Cr = C / 16;
     CbamSave sv = carve(save, N, C, P);
+    if (!chan) cbam_fill(sv.cg, 1.f, NC, s);
+    if (!spat) cbam_fill(sv.sg, 1.f, (long)N * P, s);
+    if (chan) {
     hipLaunchKernelGGL(cbam_chan_pool_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, sv.avg, sv.mx, sv.amax_hw, NC, P);
     hipLaunchKernelGGL(cbam_chan_hidden_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, sv.avg, sv.mx, w1, sv.hid, N, C);
     hipLaunchKernelGGL(cbam_chan_gate_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, sv.hid, w2, sv.cg, N, C);
+    }
+    if (spat) {
     switch (pick_pxb((long)N * P)) {
         case 64: hipLaunchKernelGGL(cbam_spatial_pool_kernel<64>, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
         case 32: hipLaunchKernelGGL(cbam_spatial_pool_kernel<32>, dim3(cdiv((long)N * P, 32)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
@@ -415,6 +430,7 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
         default: hipLaunchKernelGGL(cbam_spatial_pool_kernel<8>, dim3(cdiv((long)N * P, 8)), dim3(256), 0, s, u, sv.cg, sv.s_in, sv.amax_c, N, C, P); break;
     }
     hipLaunchKernelGGL(cbam_spatial_gate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, sv.s_in, wsp, sv.sg, N, H, W);
+    }
     const long total = (long)NC * P;
     const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3(blocks), dim3(256), 0, s, u, res, sv.cg, sv.sg, y, N, C, P, y_ctot,
@@ -426,10 +442,13 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
 extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, const float* w1, const float* w2,
                               const float* wsp, const float* save, float* du, float* dres, float* dw1, float* dw2,
                               float* dwsp, float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff,
-                              int mode, int act, float slope, void* stream) {
+                              int mode, int act, float slope, int parts, void* stream) {
     int rc = cbam_check(N, C, H, W, y_ctot, y_coff, mode, act);
     if (rc) return rc;
-    if (!u || !y || !dy || !w1 || !w2 || !wsp || !save || !du || !scratch || (mode == 2 && !dres)) return MGVAE_EINVAL;
+    if (parts < 1 || parts > 3) return MGVAE_EINVAL;
+    const bool chan = parts & 1, spat = parts & 2;
+    if (!u || !y || !dy || !save || !du || !scratch || (mode == 2 && !dres) || (chan && (!w1 || !w2)) || (spat && !wsp))
+        return MGVAE_EINVAL;
     hipStream_t s = as_stream(stream);
     const int P = H * W, NC = N * C, Cr = C / 16;
     CbamSave sv = carve(const_cast<float*>(save), N, C, P);
@@ -439,6 +458,10 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     float* davg = dcg + NC;
     float* dmaxp = davg + NC;
     float* dh = dmaxp + NC;                      // [N,2,Cr]
+    if (!spat) {
+        cbam_fill(ds_in, 0.f, (long)2 * N * P, s);          // no spatial gate: its pooled inputs get no gradient
+        cbam_fill(reinterpret_cast<float*>(sv.amax_c), 0.f, (long)N * P, s);
+    } else {
     switch (pick_pxb((long)N * P)) {
         case 64: hipLaunchKernelGGL(cbam_bwd_spatial_kernel<64>, dim3(cdiv((long)N * P, 64)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt, N, C, P, y_ctot, y_coff, mode, act, slope); break;
         case 32: hipLaunchKernelGGL(cbam_bwd_spatial_kernel<32>, dim3(cdiv((long)N * P, 32)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, dt, N, C, P, y_ctot, y_coff, mode, act, slope); break;
@@ -447,8 +470,10 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     }
     hipLaunchKernelGGL(cbam_bwd_sgate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, dt, sv.s_in, wsp, ds_in,
                        dwsp, N, H, W);
+    }
     hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
                        sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
+    if (!chan) { MGVAE_CHECK_LAUNCH(); return MGVAE_OK; }   // no channel gate: du is complete
     hipLaunchKernelGGL(cbam_bwd_dpre_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dcg, sv.cg, NC);
     hipLaunchKernelGGL(cbam_bwd_dh_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, dcg, sv.hid, w2, dh, N, C);
     hipLaunchKernelGGL(cbam_bwd_dpool_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dh, w1, davg, dmaxp, N, C);

@@ -18,7 +18,8 @@ class ChannelAttention(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x):
-        raise NotImplementedError("ChannelAttention runs inside the fused CBAM HIP op; call CBAM(channel)(x)")
+        """x * sigmoid(MLP(avg_hw x) + MLP(max_hw x)) -- the channel half of the fused CBAM op"""
+        return HF.cbam(x, self.conv1.weight, self.conv2.weight, None, 0, parts=1)
 
 
 class SpatialAttention(nn.Module):
@@ -30,7 +31,8 @@ class SpatialAttention(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x):
-        raise NotImplementedError("SpatialAttention runs inside the fused CBAM HIP op; call CBAM(channel)(x)")
+        """x * sigmoid(conv3x3([mean_c x, max_c x])) -- the spatial half of the fused CBAM op"""
+        return HF.cbam(x, None, None, self.conv.weight, 0, parts=2)
 
 
 class CBAM(nn.Module):

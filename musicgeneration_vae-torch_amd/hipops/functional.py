@@ -365,7 +365,7 @@ class _CbamFn(torch.autograd.Function):
     """graph/cbam.py CBAM.forward fused with the residual/activation that follows it."""
 
     @staticmethod
-    def forward(ctx, u, res, w1, w2, wsp, mode, act, slope, out):
+    def forward(ctx, u, res, w1, w2, wsp, mode, act, slope, out, parts):
         _need_cuda(u, "cbam")
         u = u.contiguous()
         N, C, H, W = u.shape
@@ -376,15 +376,15 @@ class _CbamFn(torch.autograd.Function):
         yct = _pitch(y)
         save = torch.empty((L.mgvae_cbam_save_floats(N, C, H, W),), device=u.device, dtype=torch.float32)
         nat.check(L.mgvae_cbam_fwd(_p(u), _p(res), _p(w1), _p(w2), _p(wsp), _p(y), _p(save), N, C, H, W, yct, 0, mode, act,
-                                   slope, _s()), "cbam_fwd")
+                                   slope, parts, _s()), "cbam_fwd")
         ctx.save_for_backward(u, y, w1, w2, wsp, save)
-        ctx.cfg = (mode, act, slope)
+        ctx.cfg = (mode, act, slope, parts)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         u, y, w1, w2, wsp, save = ctx.saved_tensors
-        mode, act, slope = ctx.cfg
+        mode, act, slope, parts = ctx.cfg
         N, C, H, W = u.shape
         L = nat.lib()
         yct = _pitch(y)
@@ -394,16 +394,17 @@ class _CbamFn(torch.autograd.Function):
         du = torch.empty_like(u)
         dres = torch.empty_like(u) if mode == 2 else None
         scratch = torch.empty((L.mgvae_cbam_bwd_scratch_floats(N, C, H, W),), device=u.device, dtype=torch.float32)
-        dw1 = grad_slot(w1) if w1.requires_grad else None
-        dw2 = grad_slot(w2) if w2.requires_grad else None
-        dws = grad_slot(wsp) if wsp.requires_grad else None
+        dw1 = grad_slot(w1) if w1 is not None and w1.requires_grad else None
+        dw2 = grad_slot(w2) if w2 is not None and w2.requires_grad else None
+        dws = grad_slot(wsp) if wsp is not None and wsp.requires_grad else None
         nat.check(L.mgvae_cbam_bwd(_p(u), _p(y), _p(dy), _p(w1), _p(w2), _p(wsp), _p(save), _p(du), _p(dres), _p(dw1), _p(dw2),
-                                   _p(dws), _p(scratch), N, C, H, W, yct, 0, mode, act, slope, _s()), "cbam_bwd")
-        return du, dres, None, None, None, None, None, None, None
+                                   _p(dws), _p(scratch), N, C, H, W, yct, 0, mode, act, slope, parts, _s()), "cbam_bwd")
+        return du, dres, None, None, None, None, None, None, None, None
 
 
-def cbam(u, w1, w2, wsp, mode=0, res=None, act=ACT_NONE, slope=0.01, out=None):
-    return _CbamFn.apply(u, res, w1, w2, wsp, mode, act, slope, out)
+def cbam(u, w1, w2, wsp, mode=0, res=None, act=ACT_NONE, slope=0.01, out=None, parts=3):
+    """parts: 3 = full CBAM, 1 = channel attention only (wsp may be None), 2 = spatial attention only"""
+    return _CbamFn.apply(u, res, w1, w2, wsp, mode, act, slope, out, parts)
 
 
 # ============================================================================ plumbing

@@ -583,3 +583,25 @@ def test_discriminators_against_oracle_and_golden(golden_dir, mode):
             assert p.grad is None or p.grad.abs().max().item() == 0, n
             continue
         check_grad("BarDiscriminator[%s] d%s" % (mode, n), p.grad, osd[n].grad, tol, atol=1e-6 * gscale, ref32=o32sd[n].grad)
+
+
+def test_standalone_channel_and_spatial_attention():
+    """graph.cbam.ChannelAttention / SpatialAttention used on their own (reference graph/cbam.py:7-52)"""
+    from graph.cbam import ChannelAttention, SpatialAttention
+    x = torch.randn(3, 64, 12, 7)
+    dy = torch.randn(3, 64, 12, 7, dtype=torch.float64)
+    sd = {"conv1.weight": torch.randn(4, 64, 1, 1) * 0.2, "conv2.weight": torch.randn(64, 4, 1, 1) * 0.2}
+    ca = ChannelAttention(64); ca.load_state_dict(sd); ca = ca.to(dev)
+    xr = x.double().requires_grad_(True); sdr = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    yr = R.channel_attention(sdr, "", xr); yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); y = ca(xd); y.backward(dy.float().to(dev))
+    check("ChannelAttention fwd", y, yr); check("ChannelAttention dx", xd.grad, xr.grad)
+    check("ChannelAttention dconv1", ca.conv1.weight.grad, sdr["conv1.weight"].grad)
+    check("ChannelAttention dconv2", ca.conv2.weight.grad, sdr["conv2.weight"].grad)
+    sd = {"conv.weight": torch.randn(1, 2, 3, 3) * 0.3}
+    sa = SpatialAttention(); sa.load_state_dict(sd); sa = sa.to(dev)
+    xr = x.double().requires_grad_(True); sdr = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    yr = R.spatial_attention(sdr, "", xr); yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); y = sa(xd); y.backward(dy.float().to(dev))
+    check("SpatialAttention fwd", y, yr); check("SpatialAttention dx", xd.grad, xr.grad)
+    check("SpatialAttention dconv", sa.conv.weight.grad, sdr["conv.weight"].grad)
