@@ -156,6 +156,12 @@ int mgvae_rowmean_bwd(const float* dout, float* dx, int rows, int L, void* strea
  * front-ends (graph/bar_discriminator.py:32-34: 60 -> 12 groups of 5; :86-87: sum over 60)      */
 int mgvae_group_sum_fwd(const float* x, float* out, size_t rows, int groups, int gsize, void* stream);
 int mgvae_group_sum_bwd(const float* dout, float* dx, size_t rows, int groups, int gsize, void* stream);
+/* Refiner pieces (graph/refiner.py:11-58): MaxPool2d(2) with saved argmax (0..3), a plain
+ * activation pass, and out = a*x + b*y (residual adds, the final (x + y) * 0.5)                 */
+int mgvae_maxpool2_fwd(const float* x, float* y, int* idx, size_t planes, int H, int W, void* stream);
+int mgvae_maxpool2_bwd(const float* dy, const int* idx, float* dx, size_t planes, int H, int W, void* stream);
+int mgvae_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream);
+int mgvae_axpby(const float* x, const float* y, float* out, float a, float b, size_t n, void* stream);
 /* nn.Embedding gather (graph/decoder.py:187,193) into a row-sliced destination and its
  * scatter-add gradient                                                                */
 int mgvae_embedding_fwd(const int64_t* idx, const float* table, float* out, int B, int D, int rows,

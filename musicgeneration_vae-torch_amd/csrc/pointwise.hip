@@ -111,6 +111,72 @@ extern "C" int mgvae_group_sum_bwd(const float* dout, float* dx, size_t rows, in
     return MGVAE_OK;
 }
 
+// ------------------------------------------------------------------ MaxPool2d(2) / activation / axpby (Refiner, graph/refiner.py)
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx,
+                                                           long planes, int H, int W, int OH, int OW) {
+    const long total = planes * OH * OW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pl = i / (OH * OW); const int r = (int)(i - pl * OH * OW);
+        const int oh = r / OW, ow = r - oh * OW;
+        const float* xp = x + pl * H * W + (2 * oh) * W + 2 * ow;
+        float m = xp[0]; int mi = 0;
+        if (xp[1] > m) { m = xp[1]; mi = 1; }
+        if (xp[W] > m) { m = xp[W]; mi = 2; }
+        if (xp[W + 1] > m) { m = xp[W + 1]; mi = 3; }
+        y[i] = m; idx[i] = mi;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                           float* __restrict__ dx, long planes, int H, int W, int OH, int OW) {
+    const long total = planes * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pl = i / (H * W); const int r = (int)(i - pl * H * W);
+        const int h = r / W, w = r - h * W;
+        const int oh = h >> 1, ow = w >> 1;
+        float v = 0.f;
+        if (oh < OH && ow < OW) {
+            const long o = pl * OH * OW + oh * OW + ow;
+            if (idx[o] == ((h & 1) << 1 | (w & 1))) v = dy[o];
+        }
+        dx[i] = v;
+    }
+}
+extern "C" int mgvae_maxpool2_fwd(const float* x, float* y, int* idx, size_t planes, int H, int W, void* stream) {
+    if (!x || !y || !idx || planes == 0 || H < 2 || W < 2) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(planes * (H / 2) * (W / 2))), dim3(256), 0, as_stream(stream), x, y, idx,
+                       (long)planes, H, W, H / 2, W / 2);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+extern "C" int mgvae_maxpool2_bwd(const float* dy, const int* idx, float* dx, size_t planes, int H, int W, void* stream) {
+    if (!dy || !dx || !idx || planes == 0 || H < 2 || W < 2) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(planes * H * W)), dim3(256), 0, as_stream(stream), dy, idx, dx,
+                       (long)planes, H, W, H / 2, W / 2);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = apply_act(x[i], act, slope);
+}
+extern "C" int mgvae_act_fwd(const float* x, float* y, size_t n, int act, float slope, void* stream) {
+    if (!x || !y || n == 0) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, n, act, slope);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                                    float a, float b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a * x[i] + b * y[i];
+}
+extern "C" int mgvae_axpby(const float* x, const float* y, float* out, float a, float b, size_t n, void* stream) {
+    if (!x || !y || !out || n == 0) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, out, a, b, n);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
 // ------------------------------------------------------------------ embedding
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table,
                                                             float* __restrict__ out, int B, int D, int rows, size_t pitch) {

@@ -9,6 +9,7 @@ from torch import nn
 from graph.decoder import Decoder
 from graph.encoder import Encoder
 from graph.phrase_encoder import PhraseModel
+from graph.refiner import Refiner
 from graph.weights_initializer import weights_init
 
 
@@ -18,8 +19,9 @@ class Model(nn.Module):
         self.encoder = Encoder([64, 128, 256, 512, 1024])
         self.decoder = Decoder([1024, 512, 256, 128, 64])
         self.phrase_encoder = PhraseModel([64, 128, 256, 512, 1024])
-        if use_refiner:
-            raise NotImplementedError("Refiner: reference defect D2 (graph/refiner.py:19); scheduled after the hot path")
+        self.use_refiner = bool(use_refiner)
+        if self.use_refiner:
+            self.refiner = Refiner()          # D2-fixed (layer2 takes 2 channels); parity unpinned
         self.apply(weights_init)
 
     def forward(self, note, pre_note, phrase, position, is_train=True):
@@ -28,6 +30,9 @@ class Model(nn.Module):
         if is_train:
             z = self.encoder(note)
             gen = self.decoder(z, pre_z, phrase_feature, position)
+            if self.use_refiner:
+                gen = self.refiner(gen)
             return gen, z, pre_z, phrase_feature
         # sampling: ``note`` is a latent [B,1152]
-        return self.decoder(note, pre_z, phrase_feature, position)
+        gen = self.decoder(note, pre_z, phrase_feature, position)
+        return self.refiner(gen) if self.use_refiner else gen

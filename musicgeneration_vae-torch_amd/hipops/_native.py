@@ -53,6 +53,10 @@ SIGNATURES = {
     "mgvae_act_bwd": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
     "mgvae_copy2d": (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     "mgvae_add_inplace": (c_int, [P, P, c_size_t, P]),
+    "mgvae_maxpool2_fwd": (c_int, [P, P, P, c_size_t, c_int, c_int, P]),
+    "mgvae_maxpool2_bwd": (c_int, [P, P, P, c_size_t, c_int, c_int, P]),
+    "mgvae_act_fwd": (c_int, [P, P, c_size_t, c_int, c_float, P]),
+    "mgvae_axpby": (c_int, [P, P, P, c_float, c_float, c_size_t, P]),
     "mgvae_rowmean_fwd": (c_int, [P, P, c_int, c_int, P]),
     "mgvae_rowmean_bwd": (c_int, [P, P, c_int, c_int, P]),
     "mgvae_embedding_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_size_t, P]),

@@ -331,6 +331,89 @@ def group_sum(x, gsize):
     return _GroupSumFn.apply(x, gsize)
 
 
+class _MaxPool2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=2) (graph/refiner.py:16,23)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "maxpool2")
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.int32)
+        nat.check(nat.lib().mgvae_maxpool2_fwd(_p(x), _p(y), _p(idx), N * C, H, W, _s()), "maxpool2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_maxpool2_bwd(_p(dy), _p(idx), _p(dx), N * C, H, W, _s()), "maxpool2_bwd")
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2Fn.apply(x)
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _need_cuda(x, "activation")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        nat.check(nat.lib().mgvae_act_fwd(_p(x), _p(y), x.numel(), act, slope, _s()), "act_fwd")
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        y4 = y.reshape(y.shape[0], -1, 1, 1)
+        return _act_bwd(y4, dy.reshape(y4.shape), act, slope).reshape(y.shape), None, None
+
+
+def activation(x, act, slope=0.01):
+    return _ActFn.apply(x, act, slope)
+
+
+class _AxpbyFn(torch.autograd.Function):
+    """a * x + b * y"""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        _need_cuda(x, "axpby")
+        x, y = x.contiguous(), y.contiguous()
+        out = torch.empty_like(x)
+        nat.check(nat.lib().mgvae_axpby(_p(x), _p(y), _p(out), a, b, x.numel(), _s()), "axpby")
+        ctx.ab = (a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        a, b = ctx.ab
+        d = d.contiguous()
+        z = torch.zeros_like(d)
+
+        def scaled(c):
+            if c == 1.0:
+                return d
+            o = torch.empty_like(d)
+            nat.check(nat.lib().mgvae_axpby(_p(d), _p(z), _p(o), c, 0.0, d.numel(), _s()), "axpby_bwd")
+            return o
+        return scaled(a), scaled(b), None, None
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    return _AxpbyFn.apply(x, y, a, b)
+
+
 class _CatTimeFn(torch.autograd.Function):
     """torch.cat((a, b), dim=2) for single-channel rolls [B,1,Ha,W] + [B,1,Hb,W] (the 2-bar pairs
     the bar discriminator sees: agent/barGen_with_gan.py:487-490)"""

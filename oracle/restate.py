@@ -197,6 +197,21 @@ def decoder(sd, p, z, pre_z, phrase_feature, position, train=False, drop_masks=N
     return (gen, pre) if return_logits else gen
 
 
+def refiner(sd, p, x, train=True):
+    """graph/refiner.py:49-58 with layer2 taking 2 input channels (the evident intent; the reference's
+    Conv2d(1, 8) raises: defect D2).  UNPINNED: the reference cannot produce a value."""
+    def bn(q, t):
+        return _bn(sd, q, t, train, 0.1)
+    x_2 = F.max_pool2d(F.leaky_relu(bn(p + "layer1.1.", F.conv2d(x, sd[p + "layer1.0.weight"], sd[p + "layer1.0.bias"], padding=2)), 0.2), 2)
+    x_8 = F.max_pool2d(F.leaky_relu(bn(p + "layer2.1.", F.conv2d(x_2, sd[p + "layer2.0.weight"], sd[p + "layer2.0.bias"], padding=2)), 0.2), 2)
+    f = F.relu(F.linear(x_8.reshape(-1, 2880), sd[p + "layer3.0.weight"], sd[p + "layer3.0.bias"]))
+    f = F.relu(F.linear(f, sd[p + "layer4.0.weight"], sd[p + "layer4.0.bias"]))
+    x_8_t = x_8 + f.view(-1, 8, 24, 15)
+    x_2_t = x_2 + F.relu(bn(p + "layer5.1.", F.conv_transpose2d(x_8_t, sd[p + "layer5.0.weight"], stride=2, padding=1)))
+    y = torch.sigmoid(bn(p + "layer6.1.", F.conv_transpose2d(x_2_t, sd[p + "layer6.0.weight"], stride=2, padding=1)))
+    return (x + y) * 0.5
+
+
 # ---------------------------------------------------------------- generator wrappers
 def generator_train(sd, note, pre_note, phrase, position, train=False, drop_masks=None, p=""):
     """graph/model.py:22-33 minus the Refiner (defect D2: the reference's Refiner raises;

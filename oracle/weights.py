@@ -137,6 +137,17 @@ def manifest_bar_discriminator(p=""):
     return m
 
 
+def manifest_refiner(p=""):
+    """graph/refiner.py state_dict with the D2 fix (layer2.0.weight is [8,2,4,4], not [8,1,4,4])"""
+    m = [(p + "layer1.0.weight", (2, 1, 4, 4), "conv_w"), (p + "layer1.0.bias", (2,), "lin_b")] + _bnm(p + "layer1.1.", 2)
+    m += [(p + "layer2.0.weight", (8, 2, 4, 4), "conv_w"), (p + "layer2.0.bias", (8,), "lin_b")] + _bnm(p + "layer2.1.", 8)
+    m += [(p + "layer3.0.weight", (1024, 2880), "lin_w"), (p + "layer3.0.bias", (1024,), "lin_b")]
+    m += [(p + "layer4.0.weight", (2880, 1024), "lin_w"), (p + "layer4.0.bias", (2880,), "lin_b")]
+    m += [(p + "layer5.0.weight", (8, 2, 4, 4), "convT_w")] + _bnm(p + "layer5.1.", 2)
+    m += [(p + "layer6.0.weight", (2, 1, 4, 4), "convT_w")] + _bnm(p + "layer6.1.", 1)
+    return m
+
+
 def _fan_in(shape, kind):
     if kind in ("conv_w",):
         return shape[1] * shape[2] * shape[3]

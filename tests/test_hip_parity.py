@@ -605,3 +605,35 @@ def test_standalone_channel_and_spatial_attention():
     xd = x.to(dev).requires_grad_(True); y = sa(xd); y.backward(dy.float().to(dev))
     check("SpatialAttention fwd", y, yr); check("SpatialAttention dx", xd.grad, xr.grad)
     check("SpatialAttention dconv", sa.conv.weight.grad, sdr["conv.weight"].grad)
+
+
+def test_refiner_d2_fixed_against_oracle():
+    """graph.refiner.Refiner with the D2 fix (layer2 takes 2 channels).  Parity UNPINNED by the
+    reference (it raises there); checked against the oracle's restatement of the same intent."""
+    from graph.refiner import Refiner
+    sd = W.make_state_dict(W.manifest_refiner(), 0, "wc")
+    m = Refiner(); m.load_state_dict(sd); m = m.to(dev).train()
+    x = torch.rand(3, 1, 96, 60)
+    osd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else
+               (v.clone().double() if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+    xr = x.double().requires_grad_(True)
+    yr = R.refiner(osd, "", xr, train=True)
+    dy = torch.randn_like(yr); yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    check("Refiner fwd", y, yr)
+    y.backward(dy.float().to(dev))
+    check_grad("Refiner dx", xd.grad, xr.grad)
+    gscale = max(v.grad.abs().max().item() for v in osd.values() if getattr(v, "grad", None) is not None)
+    for n, p in m.named_parameters():
+        check_grad("Refiner d" + n, p.grad, osd[n].grad, atol=1e-6 * gscale)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            check("Refiner " + k, v, osd[k])
+    # and inside the generator wrapper (graph/model.py:22-41 with use_refiner=True)
+    from graph.model import Model
+    g = Model(use_refiner=True).to(dev).eval()
+    note, pre, phrase, pos = W.make_inputs(2, seed=5)
+    with torch.no_grad():
+        out = g(torch.randn(2, 1152, device=dev), pre.to(dev), phrase.to(dev), pos.to(dev), False)
+    assert tuple(out.shape) == (2, 1, 96, 60) and torch.isfinite(out).all()
