@@ -13,8 +13,9 @@ class _ConvTrunk(nn.Module):
     pool_hw = (3, 2)
     linear_bias = True
 
-    def __init__(self, layers):
+    def __init__(self, layers, variational=False):
         super().__init__()
+        self.variational = bool(variational)
         self.time_pitch = TimePitchModule()
         self.pitch_time = PitchTimeModule()
         blocks = []
@@ -22,6 +23,12 @@ class _ConvTrunk(nn.Module):
             blocks += [ResidualModule(cin), PoolingModule(cin, cout)]
         self.layers = nn.ModuleList(blocks)
         self.linear = Linear(1024, 1152, bias=self.linear_bias)
+        if self.variational:
+            # optional VAE head of the archived model (old/graphs/models/bar_v1/encoder.py:54-63):
+            # ``linear`` gives the mean, ``var`` the log-variance; off by default so the parameter set
+            # and semantics of graph/encoder.py are unchanged
+            self.var = Linear(1024, 1152, bias=False)
+        self.last_kl = None
         self.apply(weights_init)
 
     def forward(self, x):
@@ -34,7 +41,13 @@ class _ConvTrunk(nn.Module):
             o = blk(o)
         if tuple(o.shape[2:]) != self.pool_hw:
             raise RuntimeError("AvgPool2d%s expects a %s map, got %s" % (self.pool_hw, self.pool_hw, tuple(o.shape[2:])))
-        return self.linear(HF.global_avg_pool(o))
+        feat = HF.global_avg_pool(o)
+        mean = self.linear(feat)
+        if not self.variational:
+            return mean
+        # reparameterisation sampler + KL term as one HIP op (eps from the Philox stream)
+        z, self.last_kl = HF.reparam_kl(mean, self.var(feat))
+        return z if self.training else mean
 
 
 class Encoder(_ConvTrunk):

@@ -637,3 +637,25 @@ def test_refiner_d2_fixed_against_oracle():
     with torch.no_grad():
         out = g(torch.randn(2, 1152, device=dev), pre.to(dev), phrase.to(dev), pos.to(dev), False)
     assert tuple(out.shape) == (2, 1, 96, 60) and torch.isfinite(out).all()
+
+
+def test_variational_encoder_flag():
+    """Encoder(variational=True): mean / log-variance heads + fused reparameterise + KL
+    (old/graphs/models/bar_v1/encoder.py:60-63, old/graphs/losses/loss.py:14-17); default stays off."""
+    from graph.encoder import Encoder
+    enc0 = Encoder([64, 128, 256, 512, 1024])
+    assert "var.weight" not in enc0.state_dict()
+    enc = Encoder([64, 128, 256, 512, 1024], variational=True).to(dev).train()
+    with torch.no_grad():
+        enc.var.weight.mul_(1e-3)         # keep exp(logvar) finite under the N(-1,1) init
+        enc.linear.weight.mul_(1e-3)
+    x = (torch.rand(2, 1, 96, 60) < 0.05).float().to(dev)
+    z = enc(x)
+    kl = enc.last_kl
+    assert tuple(z.shape) == (2, 1152) and torch.isfinite(z).all() and torch.isfinite(kl) and kl.item() >= 0
+    (z.sum() * 1e-3 + kl * 1e-3).backward()
+    assert enc.var.weight.grad.abs().max().item() > 0 and enc.linear.weight.grad.abs().max().item() > 0
+    enc.eval()
+    with torch.no_grad():
+        # eval returns the mean (no sampling); split-K atomics make the last bits run-dependent
+        assert torch.allclose(enc(x), enc(x), rtol=1e-5, atol=1e-6)
