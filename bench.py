@@ -112,12 +112,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
+    local_rank = local_rank % max(1, torch.cuda.device_count())   # tests may stack ranks on one GPU (gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("MGVAE_DIST_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm; gloo only for tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch one process per GPU (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
 
     import __graft_entry__ as ge
@@ -177,8 +182,8 @@ def main():
         L.mgvae_prof_enable(1)
         step(*batch)
         torch.cuda.synchronize()
-        recs = (nat.ProfRec * 16)()
-        n = L.mgvae_prof_collect(recs, 16)
+        recs = (nat.ProfRec * 32)()
+        n = L.mgvae_prof_collect(recs, 32)
         L.mgvae_prof_enable(0)
         L.mgvae_prof_detail(b"")
         fam = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,

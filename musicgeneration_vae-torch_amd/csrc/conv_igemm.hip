@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     constexpr bool A_IK = (MODE != MODE_BWD_DATA);   // weights [cy][k] / dY [cy][pix]: k contiguous
     constexpr bool B_KJ = (MODE != MODE_BWD_WEIGHT); // gathers with pixels along lanes
     // K tile: 16 for the 128x128 tile (LDS), 32 for the narrower tiles (half the barriers per MFMA)
-    constexpr int BKc = (TI * TJ == 4) ? 16 : 32;
+    constexpr int BKc = (TI * TJ >= 4) ? 16 : 32;
     constexpr int LDPc = BKc + 1;          // padded row length of the "row-major, k fastest" LDS images
     constexpr int RP = 256 / BKc;          // rows per pass of the "lanes along k" loaders
     constexpr int A_ELEMS = A_IK ? IT * LDPc : BKc * IT;
@@ -511,12 +511,17 @@ static int pick_tile(long Itot, long Jtot, int Z, long Kmin, int* ksplit, bool a
     const long maxsplit = (allow_split && Kmin / (BK * 8) > 1) ? Kmin / (BK * 8) : 1;
     if (wgs(ti, tj) * maxsplit < want && tj == 2) tj = 1;
     if (wgs(ti, tj) * maxsplit < want && ti == 2) ti = 1;
+    static const int env_tile4 = getenv("MGVAE_TILE4") ? atoi(getenv("MGVAE_TILE4")) : 0;
+    if (env_tile4 && ti == 2 && tj == 2 && Itot >= 256 && wgs(4, 2) * maxsplit >= want) ti = 4;   // 256 x 128
     long sp = cdiv(want, wgs(ti, tj));
     if (sp > maxsplit) sp = maxsplit;
     if (sp > 32) sp = 32;
     *ksplit = sp < 1 ? 1 : (int)sp;
+    if (ti == 4) return 4;
     return (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
 }
+static inline int tile_it(int tile) { return tile == 4 ? 256 : (tile & 1) ? 64 : 128; }
+static inline int tile_jt(int tile) { return tile == 4 ? 128 : (tile & 2) ? 64 : 128; }
 
 static void zero_slice(float* t, int N, int C, long P, int ctot, hipStream_t s) {
     const long row = (long)C * P, total = row * N;
@@ -535,6 +540,7 @@ static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
         case 0: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, p); break;
         case 1: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 2>), grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 1>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((igemm_kernel<MODE, 4, 2>), grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 1>), grid, dim3(256), 0, s, p); break;
     }
     MGVAE_CHECK_LAUNCH();
@@ -591,7 +597,7 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
     int ksplit = 1;
     const int tile = pick_tile(I, J, 1, (long)d->Cx * d->KH * d->KW, &ksplit);
-    const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
+    const int it = tile_it(tile), jt = tile_jt(tile);
     p.ksplit = ksplit;
     if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(y + (size_t)d->y_coff * d->OH * d->OW, d->N, d->Cy, (long)d->OH * d->OW, d->y_ctot, as_stream(stream)); }
     dim3 grid(cdiv(J, jt), cdiv(I, it), ksplit);
@@ -619,7 +625,7 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
     int ksplit = 1;
     static const int env_strided = getenv("MGVAE_STRIDED_NOSPLIT") ? atoi(getenv("MGVAE_STRIDED_NOSPLIT")) : 0;
     const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit, !(env_strided && Z > 1));
-    const int it = (tile & 1) ? 64 : 128, jt = (tile & 2) ? 64 : 128;
+    const int it = tile_it(tile), jt = tile_jt(tile);
     p.ksplit = ksplit;
     if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(x + (size_t)d->x_coff * d->H * d->W, d->N, d->Cx, (long)d->H * d->W, d->x_ctot, as_stream(stream)); }
     dim3 grid(cdiv(J, jt), cdiv(I, it), Z * ksplit);
@@ -681,8 +687,13 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
     auto ntiles = [&]() { return (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); };
     if (ntiles() * max_splits < g_cus && tj == 2) tj = 1;
     if (ntiles() * max_splits < g_cus && ti == 2) ti = 1;
+    static const int env_tile4w = getenv("MGVAE_TILE4") ? atoi(getenv("MGVAE_TILE4")) : 0;
+    if (env_tile4w && ti == 2 && tj == 2 && I >= 256) {
+        ti = 4;
+        if (ntiles() * max_splits < (long)g_cus * 2) ti = 2;
+    }
     const long tiles = ntiles();
-    const int tile = (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
+    const int tile = ti == 4 ? 4 : (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
     long splits = cdiv((long)g_cus * 3, tiles);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -714,14 +725,14 @@ extern "C" int mgvae_prof_detail(const char* path) {
 
 extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    MgvaeProfRec recs[20];
+    MgvaeProfRec recs[25];
     for (int k = 0; k < 5; ++k)
-        for (int t = 0; t < 4; ++t) recs[k * 4 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
+        for (int t = 0; t < 5; ++t) recs[k * 5 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
     for (auto& pe : g_prof_entries) {
         float ms = 0.f;
         hipEventSynchronize(pe.e1);
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
-        MgvaeProfRec& r = recs[pe.kind * 4 + pe.tile];
+        MgvaeProfRec& r = recs[pe.kind * 5 + pe.tile];
         r.launches += 1; r.ms += ms; r.flops += pe.flops;
         if (g_prof_detail) {
             const IgemmP& q = pe.p;
@@ -734,20 +745,18 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     g_prof_entries.clear();
     if (g_prof_detail) fflush(g_prof_detail);
     int n = 0;
-    for (int i = 0; i < 20 && n < cap; ++i)
+    for (int i = 0; i < 25 && n < cap; ++i)
         if (recs[i].launches > 0) out[n++] = recs[i];
     return n;
 }
 
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
-    static const char* names[20] = {
-        "igemm_kernel<0, 2, 2>", "igemm_kernel<0, 1, 2>", "igemm_kernel<0, 2, 1>", "igemm_kernel<0, 1, 1>",
-        "igemm_kernel<1, 2, 2>", "igemm_kernel<1, 1, 2>", "igemm_kernel<1, 2, 1>", "igemm_kernel<1, 1, 1>",
-        "igemm_kernel<2, 2, 2>", "igemm_kernel<2, 1, 2>", "igemm_kernel<2, 2, 1>", "igemm_kernel<2, 1, 1>",
-        "dconv_kernel<2, 2> (fwd)", "dconv_kernel<1, 2> (fwd)", "dconv_kernel<2, 1> (fwd)", "dconv_kernel<1, 1> (fwd)",
-        "dconv_kernel<2, 2> (bwd_data)", "dconv_kernel<1, 2> (bwd_data)", "dconv_kernel<2, 1> (bwd_data)", "dconv_kernel<1, 1> (bwd_data)"};
-    if (kind < 0 || kind > 4 || tile < 0 || tile > 3) return "?";
-    return names[kind * 4 + tile];
+    static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
+    static char buf[5][5][48];
+    if (kind < 0 || kind > 4 || tile < 0 || tile > 4) return "?";
+    if (kind < 3) snprintf(buf[kind][tile], 48, "igemm_kernel<%d, %s>", kind, tiles[tile]);
+    else snprintf(buf[kind][tile], 48, "dconv_kernel<%s> (%s)", tiles[tile], kind == 3 ? "fwd" : "bwd_data");
+    return buf[kind][tile];
 }
 
 extern "C" int mgvae_device_info(char* arch, size_t arch_len, int* cu_count) {
