@@ -123,3 +123,14 @@ def test_gan_agents_run_every_phase(tmp_path, which):
     assert bn
     if which != "barGen_with_gan2":   # that variant keeps the bar discriminator in eval() throughout, like the reference
         assert int(agent2.discriminator.state_dict()[bn[0]]) > 0
+
+
+def test_maker_bar_sampling_batch_of_songs():
+    """config 5 shape: the sampling loop with several independent songs in one batch"""
+    import __graft_entry__ as g
+    g.build()
+    import maker_bar
+    from graph.model import Model
+    gen = Model().to("cuda").eval()
+    roll = maker_bar.sample(gen, music_length=2, songs=3, device="cuda")
+    assert tuple(roll.shape) == (3, 768, 60) and set(roll.unique().tolist()) <= {0.0, 1.0}
