@@ -1,6 +1,6 @@
 """micro-benchmark of individual conv launches through the C ABI (HIP events, 20 reps)"""
 import sys, os, ctypes
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/musicgeneration_vae-torch_amd')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'musicgeneration_vae-torch_amd'))
 import torch
 import __graft_entry__ as g; g.build()
 from hipops import _native as nat
