@@ -547,9 +547,11 @@ static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
     return MGVAE_OK;
 }
 
+static thread_local bool t_no_prof = false;   // set while autotuning so trial launches are not recorded
+
 template <int MODE>
 static int run(int tile, dim3 grid, const IgemmP& p, hipStream_t s, double flops) {
-    if (!g_prof) return launch<MODE>(tile, grid, p, s);
+    if (!g_prof || t_no_prof) return launch<MODE>(tile, grid, p, s);
     ProfEntry pe{MODE, tile, flops, nullptr, nullptr, p, grid.x, grid.y, grid.z};
     if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess) return MGVAE_ELAUNCH;
     hipEventRecord(pe.e0, s);
@@ -585,26 +587,131 @@ extern "C" int mgvae_prof_record_end(void* token, void* stream) {
     return MGVAE_OK;
 }
 
+// ---- launch helpers: one function per mode that runs a given (tile, split) configuration -----------
+
+static int exec_fwd(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit, hipStream_t s) {
+    const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
+    const long P = (long)d->OH * d->OW;
+    float* y = p.out;
+    p.ksplit = ksplit;
+    if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(y, d->N, d->Cy, P, d->y_ctot, s); }
+    dim3 grid(cdiv(J, tile_jt(tile)), cdiv(I, tile_it(tile)), ksplit);
+    int rc = run<MODE_FWD>(tile, grid, p, s, 2.0 * I * J * d->Cx * d->KH * d->KW);
+    if (rc == MGVAE_OK && ksplit > 1 && d->act != MGVAE_ACT_NONE) act_slice(y, d->N, d->Cy, P, d->y_ctot, d->act, d->slope, s);
+    return rc;
+}
+
+static int exec_bwd_data(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit, hipStream_t s) {
+    const int Z = d->SH * d->SW;
+    const long I = d->Cx, J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
+    const long HW = (long)d->H * d->W;
+    float* x = p.out;
+    p.ksplit = ksplit;
+    if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(x, d->N, d->Cx, HW, d->x_ctot, s); }
+    dim3 grid(cdiv(J, tile_jt(tile)), cdiv(I, tile_it(tile)), Z * ksplit);
+    // algorithmic flops: every (output pixel, tap) pair that exists = same as the forward conv
+    const double flops = 2.0 * d->Cy * d->Cx * d->KH * d->KW * (double)d->N * d->OH * d->OW;
+    int rc = run<MODE_BWD_DATA>(tile, grid, p, s, flops);
+    if (rc == MGVAE_OK && ksplit > 1 && d->act != MGVAE_ACT_NONE) act_slice(x, d->N, d->Cx, HW, d->x_ctot, d->act, d->slope, s);
+    return rc;
+}
+
+static int exec_bwd_weight(const MgvaeConvDesc* d, IgemmP p, int tile, long splits, hipStream_t s) {
+    const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
+    if (splits < 1) splits = 1;
+    long kchunk = cdiv(M, splits);
+    kchunk = (kchunk + 31) / 32 * 32;
+    splits = cdiv(M, kchunk);
+    p.kchunk = (int)kchunk;
+    dim3 grid(cdiv(J, tile_jt(tile)), cdiv(I, tile_it(tile)), (unsigned)splits);
+    return run<MODE_BWD_WEIGHT>(tile, grid, p, s, 2.0 * I * J * M);
+}
+
+// ---- autotuner ("cudnn.benchmark" of the reference, agent/barGen2.py:27): the first time a
+// (mode, geometry, batch) is seen outside stream capture, every sensible (tile, split-K) pair is
+// timed with hipEvents on the caller's data and the fastest is cached for the life of the process.
+struct Choice { int tile; int split; };
+static std::map<KtabKey, Choice> g_choice;
+static std::mutex g_choice_mu;
+
+static bool autotune_on() {
+    static const int v = getenv("MGVAE_AUTOTUNE") ? atoi(getenv("MGVAE_AUTOTUNE")) : 1;
+    return v != 0;
+}
+static bool is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+static KtabKey choice_key(const MgvaeConvDesc* d, int mode, int wtrans) {
+    return KtabKey{{100 + mode + 16 * wtrans, d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->N}};
+}
+
+template <class Exec>
+static Choice tune(const std::vector<Choice>& cands, Exec&& exec, hipStream_t s) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    Choice best = cands[0];
+    float best_ms = 1e30f;
+    t_no_prof = true;
+    for (const Choice& c : cands) {
+        if (exec(c) != MGVAE_OK) continue;          // warm-up (also uploads nothing new: tables exist)
+        hipEventRecord(e0, s);
+        exec(c); exec(c);
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    t_no_prof = false;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return best;
+}
+
+static std::vector<Choice> gemm_candidates(long I, long J, int Z, long Kmin) {
+    std::vector<Choice> v;
+    const long maxsplit = Kmin / (BK * 8) > 1 ? Kmin / (BK * 8) : 1;
+    for (int tile = 0; tile < 4; ++tile) {
+        if (!(tile & 1) && I <= 64) continue;       // 128-row tiles need more than 64 rows
+        if (!(tile & 2) && J <= 64) continue;
+        const long wg = (long)cdiv(I, tile_it(tile)) * cdiv(J, tile_jt(tile)) * Z;
+        for (int sp = 1; sp <= 32; sp *= 2) {
+            if (sp > maxsplit) break;
+            if (sp > 1 && wg * sp > (long)g_cus * 12) break;        // already far more workgroups than needed
+            if (wg * sp * 8 < g_cus && sp * 2 <= maxsplit) continue;  // hopelessly under-filled
+            v.push_back(Choice{tile, sp});
+        }
+    }
+    if (v.empty()) v.push_back(Choice{3, 1});
+    return v;
+}
+
 extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
                                 float* y, void* stream) {
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !w || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
-    p.X = x; p.Wt = w; p.bias = bias; p.out = y; p.Y = nullptr;
+    p.X = x; p.Wt = w; p.bias = bias; p.out = y + (size_t)d->y_coff * d->OH * d->OW; p.Y = nullptr;
     rc = get_ktab(d, MODE_FWD, p);
     if (rc) return rc;
-    const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
+    hipStream_t s = as_stream(stream);
+    const long I = d->Cy, J = (long)d->N * d->OH * d->OW, K = (long)d->Cx * d->KH * d->KW;
+    if (autotune_on() && !is_capturing(s)) {
+        const KtabKey key = choice_key(d, MODE_FWD, 0);
+        Choice c;
+        bool have;
+        { std::lock_guard<std::mutex> lk(g_choice_mu); auto it = g_choice.find(key); have = it != g_choice.end(); if (have) c = it->second; }
+        if (!have) {
+            c = tune(gemm_candidates(I, J, 1, K), [&](const Choice& q) { return exec_fwd(d, p, q.tile, q.split, s); }, s);
+            std::lock_guard<std::mutex> lk(g_choice_mu); g_choice[key] = c;
+        }
+        return exec_fwd(d, p, c.tile, c.split, s);
+    }
     int ksplit = 1;
-    const int tile = pick_tile(I, J, 1, (long)d->Cx * d->KH * d->KW, &ksplit);
-    const int it = tile_it(tile), jt = tile_jt(tile);
-    p.ksplit = ksplit;
-    if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(y + (size_t)d->y_coff * d->OH * d->OW, d->N, d->Cy, (long)d->OH * d->OW, d->y_ctot, as_stream(stream)); }
-    dim3 grid(cdiv(J, jt), cdiv(I, it), ksplit);
-    rc = run<MODE_FWD>(tile, grid, p, as_stream(stream), 2.0 * I * J * d->Cx * d->KH * d->KW);
-    if (rc == MGVAE_OK && ksplit > 1 && d->act != MGVAE_ACT_NONE)
-        act_slice(y + (size_t)d->y_coff * d->OH * d->OW, d->N, d->Cy, (long)d->OH * d->OW, d->y_ctot, d->act, d->slope, as_stream(stream));
-    return rc;
+    const int tile = pick_tile(I, J, 1, K, &ksplit);
+    return exec_fwd(d, p, tile, ksplit, s);
 }
 
 static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias, float* x,
@@ -613,28 +720,30 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
     if (rc) return rc;
     if (!x || !w || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
-    p.Y = y; p.Wt = w; p.bias = bias; p.out = x; p.X = nullptr;
+    p.Y = y; p.Wt = w; p.bias = bias; p.out = x + (size_t)d->x_coff * d->H * d->W; p.X = nullptr;
     rc = get_ktab(d, MODE_BWD_DATA, p, wtrans);
     p.w_transposed = wtrans;
     if (rc) return rc;
+    hipStream_t s = as_stream(stream);
     const int Z = d->SH * d->SW;
     const long I = d->Cx;
     const long J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
     // smallest per-phase K: Cy * (fewest taps a phase has, at least 1)
     const long tmin = (long)(d->KH / d->SH > 0 ? d->KH / d->SH : 1) * (d->KW / d->SW > 0 ? d->KW / d->SW : 1);
+    if (autotune_on() && !is_capturing(s)) {
+        const KtabKey key = choice_key(d, MODE_BWD_DATA, wtrans);
+        Choice c;
+        bool have;
+        { std::lock_guard<std::mutex> lk(g_choice_mu); auto it = g_choice.find(key); have = it != g_choice.end(); if (have) c = it->second; }
+        if (!have) {
+            c = tune(gemm_candidates(I, J, Z, (long)d->Cy * tmin), [&](const Choice& q) { return exec_bwd_data(d, p, q.tile, q.split, s); }, s);
+            std::lock_guard<std::mutex> lk(g_choice_mu); g_choice[key] = c;
+        }
+        return exec_bwd_data(d, p, c.tile, c.split, s);
+    }
     int ksplit = 1;
-    static const int env_strided = getenv("MGVAE_STRIDED_NOSPLIT") ? atoi(getenv("MGVAE_STRIDED_NOSPLIT")) : 0;
-    const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit, !(env_strided && Z > 1));
-    const int it = tile_it(tile), jt = tile_jt(tile);
-    p.ksplit = ksplit;
-    if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(x + (size_t)d->x_coff * d->H * d->W, d->N, d->Cx, (long)d->H * d->W, d->x_ctot, as_stream(stream)); }
-    dim3 grid(cdiv(J, jt), cdiv(I, it), Z * ksplit);
-    // algorithmic flops: every (output pixel, tap) pair that exists = same as the forward conv
-    const double flops = 2.0 * d->Cy * d->Cx * d->KH * d->KW * (double)d->N * d->OH * d->OW;
-    rc = run<MODE_BWD_DATA>(tile, grid, p, as_stream(stream), flops);
-    if (rc == MGVAE_OK && ksplit > 1 && d->act != MGVAE_ACT_NONE)
-        act_slice(x + (size_t)d->x_coff * d->H * d->W, d->N, d->Cx, (long)d->H * d->W, d->x_ctot, d->act, d->slope, as_stream(stream));
-    return rc;
+    const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit);
+    return exec_bwd_data(d, p, tile, ksplit, s);
 }
 
 extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
@@ -679,30 +788,55 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
     if (!x || !dw || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
     p.X = x; p.Y = y; p.out = dw; p.Wt = nullptr; p.bias = nullptr;
+    hipStream_t s = as_stream(stream);
     const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
-    // big tiles always (they run ~1.4x the MFMA rate of 64x64); the pixel reduction supplies the
-    // parallelism through split-K, shrinking the tile only when even that cannot fill the chip
-    int ti = I > 64 ? 2 : 1, tj = J > 64 ? 2 : 1;
     const long max_splits = cdiv(M, BK * 8);
+    if (autotune_on() && !is_capturing(s)) {
+        const KtabKey key = choice_key(d, MODE_BWD_WEIGHT, 0);
+        Choice c;
+        bool have;
+        { std::lock_guard<std::mutex> lk(g_choice_mu); auto it = g_choice.find(key); have = it != g_choice.end(); if (have) c = it->second; }
+        if (!have) {
+            // trial launches accumulate, so they write a scratch gradient, never the caller's
+            float* scratch = nullptr;
+            if (hipMalloc(&scratch, (size_t)I * J * sizeof(float)) == hipSuccess) {
+                hipMemsetAsync(scratch, 0, (size_t)I * J * sizeof(float), s);
+                std::vector<Choice> cands;
+                for (int tile = 0; tile < 4; ++tile) {
+                    if (!(tile & 1) && I <= 64) continue;
+                    if (!(tile & 2) && J <= 64) continue;
+                    const long tiles = (long)cdiv(I, tile_it(tile)) * cdiv(J, tile_jt(tile));
+                    const long q = cdiv((long)g_cus * 2, tiles);
+                    long last = -1;
+                    for (long sp : {q / 2, q, q * 2, q * 4}) {
+                        if (sp < 1) sp = 1;
+                        if (sp > max_splits) sp = max_splits;
+                        if (sp == last) continue;
+                        last = sp;
+                        cands.push_back(Choice{tile, (int)sp});
+                    }
+                }
+                if (cands.empty()) cands.push_back(Choice{3, 1});
+                IgemmP ps = p; ps.out = scratch;
+                c = tune(cands, [&](const Choice& q) { return exec_bwd_weight(d, ps, q.tile, q.split, s); }, s);
+                hipStreamSynchronize(s);
+                hipFree(scratch);
+                std::lock_guard<std::mutex> lk(g_choice_mu); g_choice[key] = c;
+                have = true;
+            }
+        }
+        if (have) return exec_bwd_weight(d, p, c.tile, c.split, s);
+    }
+    // heuristic: big tiles always (they run ~1.4x the MFMA rate of 64x64); the pixel reduction supplies
+    // the parallelism through split-K, shrinking the tile only when even that cannot fill the chip
+    int ti = I > 64 ? 2 : 1, tj = J > 64 ? 2 : 1;
     auto ntiles = [&]() { return (long)cdiv(I, 64 * ti) * cdiv(J, 64 * tj); };
     if (ntiles() * max_splits < g_cus && tj == 2) tj = 1;
     if (ntiles() * max_splits < g_cus && ti == 2) ti = 1;
-    static const int env_tile4w = getenv("MGVAE_TILE4") ? atoi(getenv("MGVAE_TILE4")) : 0;
-    if (env_tile4w && ti == 2 && tj == 2 && I >= 256) {
-        ti = 4;
-        if (ntiles() * max_splits < (long)g_cus * 2) ti = 2;
-    }
-    const long tiles = ntiles();
-    const int tile = ti == 4 ? 4 : (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
-    long splits = cdiv((long)g_cus * 3, tiles);
+    const int tile = (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
+    long splits = cdiv((long)g_cus * 3, ntiles());
     if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    long kchunk = cdiv(M, splits);
-    kchunk = (kchunk + 31) / 32 * 32;
-    splits = cdiv(M, kchunk);
-    p.kchunk = (int)kchunk;
-    dim3 grid(cdiv(J, 64 * tj), cdiv(I, 64 * ti), (unsigned)splits);
-    return run<MODE_BWD_WEIGHT>(tile, grid, p, as_stream(stream), 2.0 * I * J * M);
+    return exec_bwd_weight(d, p, tile, splits, s);
 }
 
 extern "C" int mgvae_prof_enable(int on) {
