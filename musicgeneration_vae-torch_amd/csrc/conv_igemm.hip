@@ -781,11 +781,68 @@ extern "C" int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx
     return MGVAE_OK;
 }
 
+// Weight gradient of a "thin" convolution (Cx*KH*KW <= 16: the C=1 stems, K1 of SURVEY 2.2): a GEMM
+// with <= 16 columns would waste the MFMA, and it is purely HBM-bound (dY is read once).  One wave
+// per (n, cy) plane keeps the <= 16 partial sums in registers, pixels on the lanes (coalesced dY
+// reads), shuffle-reduces and adds one value per (cy, j) with an atomic.
+template <int JMAX>
+__global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, int J) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= p.N * p.Cy) return;
+    const int n = nc / p.Cy, cy = nc - n * p.Cy;
+    const int P = p.OH * p.OW, HW = p.H * p.W, KK = p.KH * p.KW;
+    const float* yp = p.Y + ((size_t)n * p.y_ctot + p.y_coff + cy) * P;
+    const float* xb = p.X + ((size_t)n * p.x_ctot + p.x_coff) * HW;
+    float acc[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) acc[j] = 0.f;
+    for (int i = lane; i < P; i += 64) {
+        const float g = yp[i];
+        const int oh = i / p.OW, ow = i - oh * p.OW;
+        const int r0 = oh * p.SH - p.PH, c0 = ow * p.SW - p.PW;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            if (j < J) {
+                const int cx = j / KK, t = j - cx * KK;
+                const int kh = t / p.KW, kw = t - kh * p.KW;
+                const int r = r0 + kh, c = c0 + kw;
+                const bool ok = (unsigned)r < (unsigned)p.H && (unsigned)c < (unsigned)p.W;
+                const float v = xb[ok ? cx * HW + r * p.W + c : 0];
+                acc[j] += ok ? g * v : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        if (j < J) {
+            const float sum = wave_sum(acc[j]);
+            if (lane == 0) atomicAdd(&p.out[(size_t)cy * J + j], sum);
+        }
+    }
+}
+
 extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                                        void* stream) {
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !dw || !y) return MGVAE_EINVAL;
+    if ((long)d->Cx * d->KH * d->KW <= 16) {
+        IgemmP q = make_params(d);
+        q.X = x; q.Y = y; q.out = dw;
+        const int J = d->Cx * d->KH * d->KW;
+        void* tok = nullptr;
+        const double fl = 2.0 * d->Cy * J * (double)d->N * d->OH * d->OW;
+        g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
+        g_prof_note[5] = d->OH; g_prof_note[6] = d->OW; g_prof_note[7] = d->KH; g_prof_note[8] = d->KW; g_prof_note[9] = d->SH;
+        g_prof_note[10] = d->SW; g_prof_note[11] = cdiv((long)d->N * d->Cy, 4); g_prof_note[12] = 1; g_prof_note[13] = 1;
+        mgvae_prof_record_begin(MODE_BWD_WEIGHT, 3, fl, stream, &tok);
+        if (J <= 4) hipLaunchKernelGGL(thin_bwd_weight_kernel<4>, dim3(cdiv((long)d->N * d->Cy, 4)), dim3(256), 0, as_stream(stream), q, J);
+        else hipLaunchKernelGGL(thin_bwd_weight_kernel<16>, dim3(cdiv((long)d->N * d->Cy, 4)), dim3(256), 0, as_stream(stream), q, J);
+        mgvae_prof_record_end(tok, stream);
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
     IgemmP p = make_params(d);
     p.X = x; p.Y = y; p.out = dw; p.Wt = nullptr; p.bias = nullptr;
     hipStream_t s = as_stream(stream);

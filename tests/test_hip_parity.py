@@ -485,7 +485,7 @@ def test_train_step_against_oracle_and_golden(golden_dir):
         # (the sparse binary rolls give the stems planes full of exactly tied values, so the
         # earliest gradients are chaotic in torch fp32 as well: relative L2 <= 3e-2 also passes)
         check_grad("step d" + n, params[n].grad, g, 2 * TOL, atol=1e-6 * gscale, ref32=g32, l2_ok=3e-2)
-        assert abs(params[n].grad.double().norm().item() - gn["grad"][n][0]) <= 1e-2 * gn["grad"][n][0] + 1e-6 * gscale, n
+        assert abs(params[n].grad.double().norm().item() - gn["grad"][n][0]) <= 3e-2 * gn["grad"][n][0] + 1e-6 * gscale, n
     REPORT.append("step: worst max-norm gradient error vs fp64: hip %.3e, torch fp32 itself %.3e (mask flips; see check_grad) over %d tensors" % (
         worst, worst_ref, len(names)))
     for n in gn["unused"]:
