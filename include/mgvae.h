@@ -100,11 +100,17 @@ int mgvae_channel_sum_accum(const float* t, int N, int C, int P, int ctot, int c
  * x [N,C,P] contiguous; y is channel-sliced; stats[N*C*2] = (mean, rstd) saved for bwd */
 int mgvae_instance_norm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                             float* stats, int N, int C, int P, int y_ctot, int y_coff,
-                            float eps, int act, float slope, void* stream);
+                            float eps, int act, float slope,
+                            float* pool_avg, float* pool_max, int* pool_idx,   /* optional (all or none): fused CBAM
+                                channel pooling of y -- pass the avg/max/argmax regions of the CBAM `save` buffer */
+                            void* stream);
 /* dy is channel-sliced like y; dx contiguous; dgamma/dbeta accumulate                 */
 int mgvae_instance_norm_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
                             const float* dy, float* dx, float* dgamma, float* dbeta,
                             int N, int C, int P, int dy_ctot, int dy_coff, int act, float slope,
+                            const float* add_const, const float* add_point, const int* add_index, /* optional (all or
+                                none): dy[n,c,p] += add_const[n,c]/P + (p == add_index[n,c]) * add_point[n,c]: the
+                                deferred tail of mgvae_cbam_bwd (parts & 4) */
                             void* stream);
 
 /* ---- BatchNorm2d (graph/bar_discriminator.py:19-23,69,113-114,153; graph/refiner.py) ----------
@@ -122,6 +128,11 @@ int mgvae_batch_norm_bwd(const float* x, const float* gamma, const float* beta, 
  * mode 0: y = cbam(u)                      (graph/cbam.py CBAM.forward)
  * mode 1: y = act(u + cbam(u))             (graph/encodingBlock.py:32,63,122; decoder.py:32,62,103,140,150,213)
  * mode 2: y = act(res + cbam(u))           (graph/encodingBlock.py:94-98)
+ * `save` layout (floats): cg[NC] avg[NC] max[NC] argmax_hw[NC](int) hidden[2*N*C/16] s_in[2NP] argmax_c[NP](int)
+ * sg[NP]; bwd `scratch`: dt[NP] ds_in[2NP] dcg[NC] davg[NC] dmaxp[NC] dh[2*N*C/16].
+ * parts | 4: forward -- avg/max/argmax were already written into `save` by mgvae_instance_norm_fwd;
+ * backward -- skip the final "du += davg/P + [p==argmax] dmaxp" pass: the caller's
+ * mgvae_instance_norm_bwd applies it (add_const = davg, add_point = dmaxp, add_index = argmax_hw).
  * parts: 3 = channel then spatial attention (CBAM); 1 = ChannelAttention alone (graph/cbam.py:22-29);
  * 2 = SpatialAttention alone (:43-52).  u [N,C,P] contiguous, P = H*W; w1 [C/16,C], w2 [C,C/16], wsp [1,2,3,3].
  * Workspace `save` (floats, size mgvae_cbam_save_floats) keeps what backward needs.   */

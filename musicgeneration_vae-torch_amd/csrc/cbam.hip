@@ -409,8 +409,8 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
                               int act, float slope, int parts, void* stream) {
     int rc = cbam_check(N, C, H, W, y_ctot, y_coff, mode, act);
     if (rc) return rc;
-    if (parts < 1 || parts > 3) return MGVAE_EINVAL;
-    const bool chan = parts & 1, spat = parts & 2;
+    if ((parts & 3) == 0 || parts > 7) return MGVAE_EINVAL;
+    const bool chan = parts & 1, spat = parts & 2, pooled = parts & 4;
     if (!u || !y || !save || (mode == 2 && !res) || (chan && (!w1 || !w2)) || (spat && !wsp)) return MGVAE_EINVAL;
     hipStream_t s = as_stream(stream);
     const int P = H * W, NC = N * C, Cr = C / 16;
@@ -418,6 +418,7 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
     if (!chan) cbam_fill(sv.cg, 1.f, NC, s);
     if (!spat) cbam_fill(sv.sg, 1.f, (long)N * P, s);
     if (chan) {
+    if (!pooled)   // else mgvae_instance_norm_fwd already wrote avg / max / argmax into `save`
     hipLaunchKernelGGL(cbam_chan_pool_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, sv.avg, sv.mx, sv.amax_hw, NC, P);
     hipLaunchKernelGGL(cbam_chan_hidden_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, sv.avg, sv.mx, w1, sv.hid, N, C);
     hipLaunchKernelGGL(cbam_chan_gate_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, sv.hid, w2, sv.cg, N, C);
@@ -445,8 +446,8 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
                               int mode, int act, float slope, int parts, void* stream) {
     int rc = cbam_check(N, C, H, W, y_ctot, y_coff, mode, act);
     if (rc) return rc;
-    if (parts < 1 || parts > 3) return MGVAE_EINVAL;
-    const bool chan = parts & 1, spat = parts & 2;
+    if ((parts & 3) == 0 || parts > 7) return MGVAE_EINVAL;
+    const bool chan = parts & 1, spat = parts & 2, defer = parts & 4;
     if (!u || !y || !dy || !save || !du || !scratch || (mode == 2 && !dres) || (chan && (!w1 || !w2)) || (spat && !wsp))
         return MGVAE_EINVAL;
     hipStream_t s = as_stream(stream);
@@ -480,6 +481,7 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     if (dw1 || dw2)
         hipLaunchKernelGGL(cbam_bwd_mlp_wgrad_kernel, dim3(cdiv((long)C * Cr, 256)), dim3(256), 0, s, dcg, sv.hid, dh, sv.avg,
                            sv.mx, dw1, dw2, N, C);
+    if (defer) { MGVAE_CHECK_LAUNCH(); return MGVAE_OK; }   // the caller's InstanceNorm backward adds the tail
     const long total = (long)NC * P;
     const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(cbam_bwd_finish_kernel, dim3(blocks), dim3(256), 0, s, du, davg, dmaxp, sv.amax_hw, total, P);

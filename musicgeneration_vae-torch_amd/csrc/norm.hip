@@ -4,11 +4,23 @@
 // lane-contiguous, reductions are wavefront shuffles (no LDS round trip).
 #include "mgvae_common.h"
 
+// optional fused CBAM channel pooling of the normalised output: (avg, max, first argmax) per plane
+__device__ __forceinline__ void pool_finish(float ps, float pm, int pi, int P, int lane, float* avg, float* mx, int* idx) {
+    ps = wave_sum(ps);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(pm, o, 64);
+        const int oi = __shfl_xor(pi, o, 64);
+        if (om > pm || (om == pm && oi < pi)) { pm = om; pi = oi; }
+    }
+    if (lane == 0) { *avg = ps / (float)P; *mx = pm; *idx = pi; }
+}
+
 // ------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void instance_norm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ stats, int NC, int C, int P, int y_ctot, int y_coff,
-    float eps, int act, float slope) {
+    float eps, int act, float slope, float* __restrict__ pavg, float* __restrict__ pmax, int* __restrict__ pidx) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nc = blockIdx.x * 4 + wave;
@@ -25,7 +37,14 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_kernel(
     if (lane == 0) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
     const float g = gamma[c], b = beta[c];
     float* yp = y + ((size_t)n * y_ctot + y_coff + c) * P;
-    for (int i = lane; i < P; i += 64) yp[i] = apply_act((xp[i] - mean) * rstd * g + b, act, slope);
+    float ps = 0.f, pm = -INFINITY; int pi = 0x7fffffff;
+    for (int i = lane; i < P; i += 64) {
+        const float o = apply_act((xp[i] - mean) * rstd * g + b, act, slope);
+        yp[i] = o;
+        ps += o;
+        if (o > pm) { pm = o; pi = i; }
+    }
+    if (pavg) pool_finish(ps, pm, pi, P, lane, pavg + nc, pmax + nc, pidx + nc);
 }
 
 // ------------------------------------------------------------------------ backward
@@ -33,7 +52,7 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats, const float* __restrict__ dy, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int C, int P, int dy_ctot, int dy_coff,
-    int act, float slope) {
+    int act, float slope, const float* __restrict__ addc, const float* __restrict__ addp, const int* __restrict__ addi) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nc = blockIdx.x * 4 + wave;
@@ -44,10 +63,13 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(
     float* dxp = dx + (size_t)nc * P;
     const float mean = stats[2 * nc], rstd = stats[2 * nc + 1];
     const float g = gamma[c], b = beta[c];
+    // deferred tail of the CBAM backward: + davg/P everywhere, + dmax at the arg-max pixel
+    const float ac = addc ? addc[nc] / (float)P : 0.f, ap = addc ? addp[nc] : 0.f;
+    const int ai = addc ? addi[nc] : -1;
     float s1 = 0.f, s2 = 0.f;
     for (int i = lane; i < P; i += 64) {
         const float xh = (xp[i] - mean) * rstd;
-        float gr = dyp[i];
+        float gr = dyp[i] + ac + (i == ai ? ap : 0.f);
         if (act != MGVAE_ACT_NONE) {
             const float u = xh * g + b;
             gr *= (u > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
@@ -62,7 +84,7 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(
     const float m1 = s1 / (float)P, m2 = s2 / (float)P, k = g * rstd;
     for (int i = lane; i < P; i += 64) {
         const float xh = (xp[i] - mean) * rstd;
-        float gr = dyp[i];
+        float gr = dyp[i] + ac + (i == ai ? ap : 0.f);
         if (act != MGVAE_ACT_NONE) {
             const float u = xh * g + b;
             gr *= (u > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
@@ -78,7 +100,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ stats, int NC, int C, int P, int y_ctot, int y_coff,
-    float eps, int act, float slope) {
+    float eps, int act, float slope, float* __restrict__ pavg, float* __restrict__ pmax, int* __restrict__ pidx) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nc = blockIdx.x * 4 + wave;
@@ -108,6 +130,7 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
     if (lane == 0) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
     const float g = gamma[c], b = beta[c];
     float4* yp = reinterpret_cast<float4*>(y + ((size_t)n * y_ctot + y_coff + c) * P);
+    float ps = 0.f, pm = -INFINITY; int pi = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
@@ -118,8 +141,14 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
             o.z = apply_act((v[k].z - mean) * rstd * g + b, act, slope);
             o.w = apply_act((v[k].w - mean) * rstd * g + b, act, slope);
             yp[i] = o;
+            ps += (o.x + o.y) + (o.z + o.w);
+            if (o.x > pm) { pm = o.x; pi = 4 * i; }
+            if (o.y > pm) { pm = o.y; pi = 4 * i + 1; }
+            if (o.z > pm) { pm = o.z; pi = 4 * i + 2; }
+            if (o.w > pm) { pm = o.w; pi = 4 * i + 3; }
         }
     }
+    if (pavg) pool_finish(ps, pm, pi, P, lane, pavg + nc, pmax + nc, pidx + nc);
 }
 
 template <int NV>
@@ -127,13 +156,15 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats, const float* __restrict__ dy, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int C, int P, int dy_ctot, int dy_coff,
-    int act, float slope) {
+    int act, float slope, const float* __restrict__ addc, const float* __restrict__ addp, const int* __restrict__ addi) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nc = blockIdx.x * 4 + wave;
     if (nc >= NC) return;
     const int n = nc / C, c = nc - n * C;
     const int P4 = P >> 2;
+    const float ac = addc ? addc[nc] / (float)P : 0.f, ap = addc ? addp[nc] : 0.f;
+    const int ai = addc ? addi[nc] : -1;
     const float4* xp = reinterpret_cast<const float4*>(x + (size_t)nc * P);
     const float4* dyp = reinterpret_cast<const float4*>(dy + ((size_t)n * dy_ctot + dy_coff + c) * P);
     float4* dxp = reinterpret_cast<float4*>(dx + (size_t)nc * P);
@@ -148,6 +179,8 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
         if (i < P4) {
             const float4 xv = xp[i];
             float4 gv = dyp[i];
+            gv.x += ac; gv.y += ac; gv.z += ac; gv.w += ac;
+            if ((ai >> 2) == i) { const int q = ai & 3; if (q == 0) gv.x += ap; else if (q == 1) gv.y += ap; else if (q == 2) gv.z += ap; else gv.w += ap; }
             float4 h;
             h.x = (xv.x - mean) * rstd; h.y = (xv.y - mean) * rstd; h.z = (xv.z - mean) * rstd; h.w = (xv.w - mean) * rstd;
             if (act != MGVAE_ACT_NONE) {
@@ -334,13 +367,15 @@ extern "C" int mgvae_batch_norm_bwd(const float* x, const float* gamma, const fl
 
 extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                                        float* stats, int N, int C, int P, int y_ctot, int y_coff, float eps,
-                                       int act, float slope, void* stream) {
+                                       int act, float slope, float* pool_avg, float* pool_max, int* pool_idx,
+                                       void* stream) {
+    if ((pool_avg != nullptr) != (pool_max != nullptr) || (pool_avg != nullptr) != (pool_idx != nullptr)) return MGVAE_EINVAL;
     if (!x || !gamma || !beta || !y || !stats || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
     if (y_coff < 0 || y_coff + C > y_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
 #define MGVAE_INF(NV) hipLaunchKernelGGL(instance_norm_fwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
-                                         gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope)
+                                         gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx)
     switch (al ? pick_nv(P) : 0) {
         case 1: MGVAE_INF(1); break;
         case 2: MGVAE_INF(2); break;
@@ -348,7 +383,7 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
         case 23: MGVAE_INF(23); break;
         default:
             hipLaunchKernelGGL(instance_norm_fwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
-                               beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope);
+                               beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx);
     }
 #undef MGVAE_INF
     MGVAE_CHECK_LAUNCH();
@@ -357,13 +392,16 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
 
 extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const float* beta, const float* stats,
                                        const float* dy, float* dx, float* dgamma, float* dbeta, int N, int C,
-                                       int P, int dy_ctot, int dy_coff, int act, float slope, void* stream) {
+                                       int P, int dy_ctot, int dy_coff, int act, float slope, const float* add_const,
+                                       const float* add_point, const int* add_index, void* stream) {
+    if ((add_const != nullptr) != (add_point != nullptr) || (add_const != nullptr) != (add_index != nullptr)) return MGVAE_EINVAL;
     if (!x || !gamma || !beta || !stats || !dy || !dx || N <= 0 || C <= 0 || P <= 0) return MGVAE_EINVAL;
     if (dy_coff < 0 || dy_coff + C > dy_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
 #define MGVAE_INB(NV) hipLaunchKernelGGL(instance_norm_bwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
-                                         gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope)
+                                         gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const, \
+                                         add_point, add_index)
     switch (al ? pick_nv(P) : 0) {
         case 1: MGVAE_INB(1); break;
         case 2: MGVAE_INB(2); break;
@@ -371,7 +409,8 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
         case 23: MGVAE_INB(23); break;
         default:
             hipLaunchKernelGGL(instance_norm_bwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
-                               beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope);
+                               beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const,
+                               add_point, add_index);
     }
 #undef MGVAE_INB
     MGVAE_CHECK_LAUNCH();

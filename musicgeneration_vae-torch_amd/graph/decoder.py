@@ -29,7 +29,7 @@ class _Stem(nn.Module):
     def forward(self, x, out=None):
         o = getattr(self, self.first)(x, act=HF.ACT_RELU)
         o = getattr(self, self.second)(o)
-        return self.cbam.fused(self.bn(o), 1, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(o, self.bn, 1, act=HF.ACT_RELU, out=out)
 
 
 class TimePitchModule(_Stem):
@@ -63,8 +63,7 @@ class DeConvModule(nn.Module):
         cat = torch.empty((n, 2 * co, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
         a = self.bn1(self.deConv1(x), act=HF.ACT_RELU, out=cat[:, :co])
         b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
-        u = self.bn3(self.conv(HF.join(cat, a, b)))
-        return self.cbam.fused(u, 1, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
 
 
 class DeConvPitchPadding(nn.Module):
@@ -88,10 +87,9 @@ class DeConvPitchPadding(nn.Module):
         co = self.out_channel
         n, _, h, w = x.shape
         cat = torch.empty((n, 2 * co, 2 * h, 2 * w + 1), device=x.device, dtype=torch.float32)
-        a = self.cbam1.fused(self.bn2(self.deConv1(x)), 1, act=HF.ACT_RELU, out=cat[:, :co])
+        a = self.cbam1.fused_norm(self.deConv1(x), self.bn2, 1, act=HF.ACT_RELU, out=cat[:, :co])
         b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
-        u = self.bn3(self.conv(HF.join(cat, a, b)))
-        return self.cbam2.fused(u, 1, act=HF.ACT_RELU, out=out)
+        return self.cbam2.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
 
 
 class Decoder(nn.Module):
@@ -141,8 +139,7 @@ class Decoder(nn.Module):
         cat = new(n, 2048, 6, 3)
         pitch = self.pitch(x, out=cat[:, :1024])
         time = self.time(x, out=cat[:, 1024:])
-        u = self.bn(self.fit1(HF.join(cat, pitch, time)))
-        o = self.cbam.fused(u, 1, act=HF.ACT_RELU)
+        o = self.cbam.fused_norm(self.fit1(HF.join(cat, pitch, time)), self.bn, 1, act=HF.ACT_RELU)
         for blk in self.layers:
             o = blk(o)
         return self.fit2(o, act=HF.ACT_SIGMOID)

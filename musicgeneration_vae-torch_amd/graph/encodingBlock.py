@@ -28,8 +28,7 @@ class _Stem(nn.Module):
     def forward(self, x, out=None):
         o = getattr(self, self.first)(x, act=HF.ACT_LEAKY, slope=0.01)
         o = getattr(self, self.second)(o)
-        u = self.bn(o)
-        return self.cbam.fused(u, 1, act=HF.ACT_LEAKY, slope=0.01, out=out)
+        return self.cbam.fused_norm(o, self.bn, 1, act=HF.ACT_LEAKY, slope=0.01, out=out)
 
 
 class TimePitchModule(_Stem):
@@ -55,7 +54,7 @@ class ResidualModule(nn.Module):
 
     def forward(self, x, out=None):
         o = self.conv2(self.conv1(x, act=HF.ACT_RELU))
-        return self.cbam.fused(self.bn(o), 2, res=x, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(o, self.bn, 2, res=x, act=HF.ACT_RELU, out=out)
 
 
 class PoolingModule(nn.Module):
@@ -69,4 +68,4 @@ class PoolingModule(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
-        return self.cbam.fused(self.bn(self.conv(x)), 1, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(self.conv(x), self.bn, 1, act=HF.ACT_RELU, out=out)

@@ -40,8 +40,8 @@ SIGNATURES = {
     "mgvae_conv2d_fwd_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_conv2d_bwd_data_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_channel_sum_accum": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
-    "mgvae_instance_norm_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, P]),
-    "mgvae_instance_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "mgvae_instance_norm_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, P, P, P, P]),
+    "mgvae_instance_norm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, P, P, P]),
     "mgvae_batch_norm_fwd": (c_int, [P] * 7 + [c_int] * 4 + [c_float, c_float, c_int, c_float, P]),
     "mgvae_batch_norm_bwd": (c_int, [P] * 8 + [c_int] * 5 + [c_float, P]),
     "mgvae_group_sum_fwd": (c_int, [P, P, c_size_t, c_int, c_int, P]),

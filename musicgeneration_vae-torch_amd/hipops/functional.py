@@ -244,7 +244,7 @@ class _InstNormFn(torch.autograd.Function):
         yct = _pitch(y)
         stats = torch.empty((N * C * 2,), device=x.device, dtype=torch.float32)
         nat.check(nat.lib().mgvae_instance_norm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), N, C, H * W, yct, 0,
-                                                    eps, act, slope, _s()), "instance_norm_fwd")
+                                                    eps, act, slope, None, None, None, _s()), "instance_norm_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (act, slope)
         return y
@@ -259,7 +259,8 @@ class _InstNormFn(torch.autograd.Function):
         dg = grad_slot(gamma) if gamma.requires_grad else None
         db = grad_slot(beta) if beta.requires_grad else None
         nat.check(nat.lib().mgvae_instance_norm_bwd(_p(x), _p(gamma), _p(beta), _p(stats), _p(dy), _p(dx), _p(dg), _p(db),
-                                                    N, C, H * W, dct, 0, act, slope, _s()), "instance_norm_bwd")
+                                                    N, C, H * W, dct, 0, act, slope, None, None, None, _s()),
+                  "instance_norm_bwd")
         return dx, None, None, None, None, None, None
 
 
@@ -488,6 +489,67 @@ class _CbamFn(torch.autograd.Function):
 def cbam(u, w1, w2, wsp, mode=0, res=None, act=ACT_NONE, slope=0.01, out=None, parts=3):
     """parts: 3 = full CBAM, 1 = channel attention only (wsp may be None), 2 = spatial attention only"""
     return _CbamFn.apply(u, res, w1, w2, wsp, mode, act, slope, out, parts)
+
+
+class _NormCbamFn(torch.autograd.Function):
+    """InstanceNorm2d -> CBAM -> (+residual) -> activation as ONE autograd node (graph/encodingBlock.py:48-55,
+    110-117; graph/decoder.py:124-133,173-176).  The norm kernel also produces CBAM's channel pooling, and the
+    norm backward absorbs the tail of the CBAM backward, so the activation map is streamed two times fewer."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, w1, w2, wsp, eps, mode, act, slope, out):
+        _need_cuda(x, "norm_cbam")
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        NC = N * C
+        if res is not None:
+            res = res.contiguous()
+        L = nat.lib()
+        u = torch.empty_like(x)
+        stats = torch.empty((NC * 2,), device=x.device, dtype=torch.float32)
+        y = out if out is not None else torch.empty_like(x)
+        yct = _pitch(y)
+        save = torch.empty((L.mgvae_cbam_save_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
+        nat.check(L.mgvae_instance_norm_fwd(_p(x), _p(gamma), _p(beta), _p(u), _p(stats), N, C, H * W, C, 0, eps, ACT_NONE,
+                                            0.0, _p(save[NC:]), _p(save[2 * NC:]), _p(save[3 * NC:]), _s()),
+                  "instance_norm_fwd")
+        nat.check(L.mgvae_cbam_fwd(_p(u), _p(res), _p(w1), _p(w2), _p(wsp), _p(y), _p(save), N, C, H, W, yct, 0, mode, act,
+                                   slope, 3 | 4, _s()), "cbam_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats, u, y, w1, w2, wsp, save)
+        ctx.cfg = (mode, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats, u, y, w1, w2, wsp, save = ctx.saved_tensors
+        mode, act, slope = ctx.cfg
+        N, C, H, W = x.shape
+        NC, NP = N * C, N * H * W
+        L = nat.lib()
+        yct = _pitch(y)
+        dy, dct = _sliceable(dy)
+        if dct != yct:
+            y, dy, yct = y.contiguous(), dy.contiguous(), C
+        du = torch.empty_like(x)
+        dres = torch.empty_like(x) if mode == 2 else None
+        scratch = torch.empty((L.mgvae_cbam_bwd_scratch_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
+        dw1 = grad_slot(w1) if w1.requires_grad else None
+        dw2 = grad_slot(w2) if w2.requires_grad else None
+        dws = grad_slot(wsp) if wsp.requires_grad else None
+        nat.check(L.mgvae_cbam_bwd(_p(u), _p(y), _p(dy), _p(w1), _p(w2), _p(wsp), _p(save), _p(du), _p(dres), _p(dw1), _p(dw2),
+                                   _p(dws), _p(scratch), N, C, H, W, yct, 0, mode, act, slope, 3 | 4, _s()), "cbam_bwd")
+        dx = torch.empty_like(x)
+        dg = grad_slot(gamma) if gamma.requires_grad else None
+        db = grad_slot(beta) if beta.requires_grad else None
+        davg = scratch[3 * NP + NC:]
+        nat.check(L.mgvae_instance_norm_bwd(_p(x), _p(gamma), _p(beta), _p(stats), _p(du), _p(dx), _p(dg), _p(db), N, C,
+                                            H * W, C, 0, ACT_NONE, 0.0, _p(davg), _p(davg[NC:]), _p(save[3 * NC:]), _s()),
+                  "instance_norm_bwd")
+        return (dx, None, None, dres) + (None,) * 8
+
+
+def norm_cbam(x, gamma, beta, w1, w2, wsp, eps=1e-5, mode=0, res=None, act=ACT_NONE, slope=0.01, out=None):
+    return _NormCbamFn.apply(x, gamma, beta, res, w1, w2, wsp, eps, mode, act, slope, out)
 
 
 # ============================================================================ plumbing

@@ -252,6 +252,44 @@ def test_cbam(shape, mode, act):
         check(tag + " d" + k, ps[k].grad, sdr[k].grad)
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 48, 30), (2, 1024, 6, 3), (2, 128, 24, 15), (2, 64, 12, 7), (2, 64, 96, 61),
+                                   (1, 256, 12, 8)])
+@pytest.mark.parametrize("mode,act", [(1, 1), (1, 2), (2, 1)])
+def test_norm_cbam_fused(shape, mode, act):
+    """InstanceNorm -> CBAM -> residual -> activation as one node (pooling fused into the norm
+    forward, CBAM backward tail fused into the norm backward) against the fp64 oracle."""
+    N, C, H, W_ = shape
+    x = torch.randn(shape) * 2 + 0.5; res = torch.randn(shape)
+    g = torch.randn(C); b = torch.randn(C)
+    sd = {"channel_attention.conv1.weight": torch.randn(C // 16, C, 1, 1) * 0.2,
+          "channel_attention.conv2.weight": torch.randn(C, C // 16, 1, 1) * 0.2,
+          "spatial_attention.conv.weight": torch.randn(1, 2, 3, 3) * 0.3}
+    sdr = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    fn = (lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.01))[act]
+    ur = F.instance_norm(xr, None, None, gr, br, True, 0.01, 1e-5)
+    o = R.cbam(sdr, "", ur)
+    yr = fn(ur + o) if mode == 1 else fn(rr + o)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); rd = res.to(dev).requires_grad_(True)
+    gd = torch.nn.Parameter(g.to(dev)); bd = torch.nn.Parameter(b.to(dev))
+    ps = {k: torch.nn.Parameter(v.to(dev)) for k, v in sd.items()}
+    y = HF().norm_cbam(xd, gd, bd, ps["channel_attention.conv1.weight"], ps["channel_attention.conv2.weight"],
+                       ps["spatial_attention.conv.weight"], 1e-5, mode, rd if mode == 2 else None, act, 0.01)
+    tag = "norm_cbam %s mode%d act%d" % (shape, mode, act)
+    check(tag + " fwd", y, yr)
+    y.backward(dy.float().to(dev))
+    check(tag + " dx", xd.grad, xr.grad)
+    check(tag + " dgamma", gd.grad, gr.grad)
+    check(tag + " dbeta", bd.grad, br.grad)
+    if mode == 2:
+        check(tag + " dres", rd.grad, rr.grad)
+    for k in sd:
+        check(tag + " d" + k, ps[k].grad, sdr[k].grad)
+
+
 # ------------------------------------------------------------------------- small ops
 def test_small_ops():
     hf = HF()
