@@ -41,7 +41,19 @@ struct IgemmP {
     const int* wtab;    // bwd_data: per-K weight offset (cy * Cx * KH*KW + tap), [phase][stride]
     int ktab_stride;    // entries per phase (padded by 16 so a wave can always read its whole row group)
     int w_transposed;   // bwd_data: Wt is [Cy][KH*KW][Cx] (mgvae_weight_transpose) -> lane-contiguous A loads
+    unsigned x_bytes, y_bytes, w_bytes;   // extents of X / Y / Wt for the buffer descriptors (< 4 GiB each)
 };
+
+// Operand loads go through buffer descriptors: a masked element gets the offset 0xFFFFFFFF, which the
+// hardware range-checks and answers with 0.0f.  No select on the loaded VALUE means nothing consumes a
+// load before the LDS store that follows the MFMA block, so the whole K tile stays in flight under it.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* ptr, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, int elem, bool ok) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? elem * 4 : -1, 0, 0));
+}
 
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
 
@@ -211,9 +223,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     }
 
     float ra[NA], rb[NB];
+    const rsrc_t rX = make_rsrc(p.X, p.x_bytes), rY = make_rsrc(p.Y, p.y_bytes), rW = make_rsrc(p.Wt, p.w_bytes);
+    (void)rX; (void)rY; (void)rW;
 
-    // All loads are UNCONDITIONAL with a clamped address and a select afterwards, so the compiler
-    // emits one straight-line block: every global load of a K tile is in flight together (a
+    // All loads are UNCONDITIONAL buffer loads (masked elements are sent out of range and read as 0),
+    // so the compiler emits one straight-line block: every load of a K tile is in flight together (a
     // predicated load would be a branch + wait per element).  The per-K gather constants come from
     // the ktab table through scalar loads (the K row is wave-uniform).
     auto load_tile = [&](int k0) {
@@ -224,9 +238,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const int gi = i0 + rr + RP * r;
-                const bool ok = kok && gi < Itot;
-                const float v = p.Wt[ok ? (size_t)gi * Ktot + gk : 0];
-                ra[r] = ok ? v : 0.f;
+                const bool ok = kok & (gi < Itot);
+                ra[r] = buf_load(rW, gi * Ktot + gk, ok);
             }
         } else if constexpr (MODE == MODE_BWD_DATA) {
             const int KK = p.KH * p.KW;
@@ -237,9 +250,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             for (int r = 0; r < NA; ++r) wo[r] = wt[r];          // one scalar load (rows are contiguous)
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
-                const bool ok = ai_valid && (k0 + ikr0 + r) < kend;
-                const float v = p.Wt[ok ? wo[r] + ai_off : 0];
-                ra[r] = ok ? v : 0.f;
+                const bool ok = ai_valid & ((k0 + ikr0 + r) < kend);
+                ra[r] = buf_load(rW, wo[r] + ai_off, ok);
             }
         } else {
             const bool kok = (k0 + kl) < kend;
@@ -247,14 +259,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const int gi = i0 + rr + RP * r;
-                const bool ok = kok && gi < Itot;
-                const float v = p.Y[ok ? base + gi * P : 0];
-                ra[r] = ok ? v : 0.f;
+                const bool ok = kok & (gi < Itot);
+                ra[r] = buf_load(rY, base + gi * P, ok);
             }
         }
         // ------------------------------ B operand ------------------------------
         if constexpr (MODE != MODE_BWD_WEIGHT) {
-            const float* __restrict__ src = (MODE == MODE_FWD) ? p.X : p.Y;
+            const rsrc_t src = (MODE == MODE_FWD) ? rX : rY;
             const int2* __restrict__ kt = ktab + (k0 + jkr0);
             int2 e[NB];
 #pragma unroll
@@ -262,10 +273,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const int dh = (int)(short)(e[r].y & 0xffff), dw = e[r].y >> 16;
-                const bool ok = bj_valid && (k0 + jkr0 + r) < kend && (unsigned)(b_r0 + dh) < (unsigned)b_RH &&
-                                (unsigned)(b_c0 + dw) < (unsigned)b_RW;
-                const float v = src[ok ? b_pix + e[r].x : 0];
-                rb[r] = ok ? v : 0.f;
+                const bool ok = bj_valid & ((k0 + jkr0 + r) < kend) & ((unsigned)(b_r0 + dh) < (unsigned)b_RH) &
+                                ((unsigned)(b_c0 + dw) < (unsigned)b_RW);
+                rb[r] = buf_load(src, b_pix + e[r].x, ok);
             }
         } else {
             const bool kok = (k0 + kl) < kend;
@@ -274,10 +284,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             const int base = (w_n * p.x_ctot + p.x_coff) * HW + r0 * p.W + c0;
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const bool ok = kok && (unsigned)(r0 + bj_dh[r]) < (unsigned)p.H &&
-                                (unsigned)(c0 + bj_dw[r]) < (unsigned)p.W;
-                const float v = p.X[ok ? base + bj_off[r] : 0];
-                rb[r] = ok ? v : 0.f;
+                const bool ok = kok & ((unsigned)(r0 + bj_dh[r]) < (unsigned)p.H) &
+                                ((unsigned)(c0 + bj_dw[r]) < (unsigned)p.W);
+                rb[r] = buf_load(rX, base + bj_off[r], ok);
             }
             // advance this thread's pixel by one K tile
             w_p += BKc;
@@ -412,7 +421,8 @@ static int validate(const MgvaeConvDesc* d) {
     if (d->x_coff < 0 || d->x_coff + d->Cx > d->x_ctot) return MGVAE_EINVAL;
     if (d->y_coff < 0 || d->y_coff + d->Cy > d->y_ctot) return MGVAE_EINVAL;
     const long xe = (long)d->N * d->x_ctot * d->H * d->W, ye = (long)d->N * d->y_ctot * d->OH * d->OW;
-    if (xe >= (1L << 31) || ye >= (1L << 31) || (long)d->Cx * d->Cy * d->KH * d->KW >= (1L << 31)) return MGVAE_EINVAL;
+    // tensors are addressed through 32-bit byte offsets of buffer descriptors: < 2^30 elements each
+    if (xe >= (1L << 30) || ye >= (1L << 30) || (long)d->Cx * d->Cy * d->KH * d->KW >= (1L << 30)) return MGVAE_EINVAL;
     return MGVAE_OK;
 }
 
@@ -422,6 +432,9 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
     p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0; p.w_transposed = 0;
+    p.x_bytes = (unsigned)((size_t)d->N * d->x_ctot * d->H * d->W * 4);
+    p.y_bytes = (unsigned)((size_t)d->N * d->y_ctot * d->OH * d->OW * 4);
+    p.w_bytes = (unsigned)((size_t)d->Cx * d->Cy * d->KH * d->KW * 4);
     return p;
 }
 
@@ -634,6 +647,52 @@ struct Choice { int tile; int split; };
 static std::map<KtabKey, Choice> g_choice;
 static std::mutex g_choice_mu;
 
+// MGVAE_AUTOTUNE_FILE=<path>: decisions are appended to / preloaded from a text file (one line per key), so a
+// restarted job -- or the other ranks of a node -- skips the trial launches.
+static const char* choice_file() {
+    static const char* f = getenv("MGVAE_AUTOTUNE_FILE");
+    return (f && *f) ? f : nullptr;
+}
+static void choice_load_locked() {
+    static bool loaded = false;
+    if (loaded) return;
+    loaded = true;
+    const char* f = choice_file();
+    if (!f) return;
+    FILE* fp = fopen(f, "r");
+    if (!fp) return;
+    KtabKey k; Choice c;
+    for (;;) {
+        int n = 0;
+        for (int i = 0; i < 14; ++i) n += fscanf(fp, "%d", &k.v[i]);
+        n += fscanf(fp, "%d %d", &c.tile, &c.split);
+        if (n != 16) break;
+        if (c.tile >= 0 && c.tile < 4 && c.split >= 1 && c.split <= 4096) g_choice[k] = c;
+    }
+    fclose(fp);
+}
+static bool choice_lookup(const KtabKey& key, Choice* c) {
+    std::lock_guard<std::mutex> lk(g_choice_mu);
+    choice_load_locked();
+    auto it = g_choice.find(key);
+    if (it == g_choice.end()) return false;
+    *c = it->second;
+    return true;
+}
+static void choice_store(const KtabKey& key, const Choice& c) {
+    std::lock_guard<std::mutex> lk(g_choice_mu);
+    g_choice[key] = c;
+    if (const char* f = choice_file()) {
+        if (FILE* fp = fopen(f, "a")) {
+            char line[256]; int o = 0;
+            for (int i = 0; i < 14; ++i) o += snprintf(line + o, sizeof(line) - o, "%d ", key.v[i]);
+            snprintf(line + o, sizeof(line) - o, "%d %d\n", c.tile, c.split);
+            fputs(line, fp);     // one write per line: concurrent ranks interleave whole lines only
+            fclose(fp);
+        }
+    }
+}
+
 static bool autotune_on() {
     static const int v = getenv("MGVAE_AUTOTUNE") ? atoi(getenv("MGVAE_AUTOTUNE")) : 1;
     return v != 0;
@@ -702,10 +761,10 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
         const KtabKey key = choice_key(d, MODE_FWD, 0);
         Choice c;
         bool have;
-        { std::lock_guard<std::mutex> lk(g_choice_mu); auto it = g_choice.find(key); have = it != g_choice.end(); if (have) c = it->second; }
+        have = choice_lookup(key, &c);
         if (!have) {
             c = tune(gemm_candidates(I, J, 1, K), [&](const Choice& q) { return exec_fwd(d, p, q.tile, q.split, s); }, s);
-            std::lock_guard<std::mutex> lk(g_choice_mu); g_choice[key] = c;
+            choice_store(key, c);
         }
         return exec_fwd(d, p, c.tile, c.split, s);
     }
@@ -734,10 +793,10 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
         const KtabKey key = choice_key(d, MODE_BWD_DATA, wtrans);
         Choice c;
         bool have;
-        { std::lock_guard<std::mutex> lk(g_choice_mu); auto it = g_choice.find(key); have = it != g_choice.end(); if (have) c = it->second; }
+        have = choice_lookup(key, &c);
         if (!have) {
             c = tune(gemm_candidates(I, J, Z, (long)d->Cy * tmin), [&](const Choice& q) { return exec_bwd_data(d, p, q.tile, q.split, s); }, s);
-            std::lock_guard<std::mutex> lk(g_choice_mu); g_choice[key] = c;
+            choice_store(key, c);
         }
         return exec_bwd_data(d, p, c.tile, c.split, s);
     }
@@ -852,7 +911,7 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
         const KtabKey key = choice_key(d, MODE_BWD_WEIGHT, 0);
         Choice c;
         bool have;
-        { std::lock_guard<std::mutex> lk(g_choice_mu); auto it = g_choice.find(key); have = it != g_choice.end(); if (have) c = it->second; }
+        have = choice_lookup(key, &c);
         if (!have) {
             // trial launches accumulate, so they write a scratch gradient, never the caller's
             float* scratch = nullptr;
@@ -878,7 +937,7 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
                 c = tune(cands, [&](const Choice& q) { return exec_bwd_weight(d, ps, q.tile, q.split, s); }, s);
                 hipStreamSynchronize(s);
                 hipFree(scratch);
-                std::lock_guard<std::mutex> lk(g_choice_mu); g_choice[key] = c;
+                choice_store(key, c);
                 have = true;
             }
         }
