@@ -347,26 +347,48 @@ __global__ __launch_bounds__(256) void cbam_bwd_dpool_kernel(const float* __rest
 }
 
 // B4b: weight gradients as a batched reduction over the samples; one thread owns one (c, j)
-// pair of BOTH matrices, so the accumulation into the gradient needs no atomics.
+// pair of BOTH matrices for a chunk of samples (blockIdx.y).  Small C has few (c, j) pairs, so the
+// sample axis supplies the parallelism there (chunks > 1 -> atomic accumulation); the loop is
+// unrolled by four with independent loads so the L2 latencies overlap instead of chaining.
 //   dw2[c][j] += sum_n dpre[n,c] * (ha[n,j] + hm[n,j])
 //   dw1[j][c] += sum_n dha[n,j] * avg[n,c] + dhm[n,j] * max[n,c]
 __global__ __launch_bounds__(256) void cbam_bwd_mlp_wgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ hid,
                                                                  const float* __restrict__ dh, const float* __restrict__ avg,
                                                                  const float* __restrict__ mx, float* __restrict__ dw1,
-                                                                 float* __restrict__ dw2, int N, int C) {
+                                                                 float* __restrict__ dw2, int N, int C, int per) {
     const int Cr = C / 16;
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= C * Cr) return;
     const int c = f / Cr, j = f - c * Cr;
+    const int n0 = blockIdx.y * per, n1 = min(N, n0 + per);
     float a2 = 0.f, a1 = 0.f;
-    for (int n = 0; n < N; ++n) {
+    int n = n0;
+    for (; n + 4 <= n1; n += 4) {
+        float d[4], ha[4], hm[4], da[4], dm[4], av[4], mv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* hn = hid + (size_t)(n + q) * 2 * Cr;
+            const float* dn = dh + (size_t)(n + q) * 2 * Cr;
+            d[q] = dpre[(size_t)(n + q) * C + c]; ha[q] = hn[j]; hm[q] = hn[Cr + j];
+            da[q] = dn[j]; dm[q] = dn[Cr + j];
+            av[q] = avg[(size_t)(n + q) * C + c]; mv[q] = mx[(size_t)(n + q) * C + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a2 += d[q] * (ha[q] + hm[q]); a1 += da[q] * av[q] + dm[q] * mv[q]; }
+    }
+    for (; n < n1; ++n) {
         const float* hn = hid + (size_t)n * 2 * Cr;
         const float* dn = dh + (size_t)n * 2 * Cr;
         a2 += dpre[(size_t)n * C + c] * (hn[j] + hn[Cr + j]);
         a1 += dn[j] * avg[(size_t)n * C + c] + dn[Cr + j] * mx[(size_t)n * C + c];
     }
-    if (dw2) dw2[(size_t)c * Cr + j] += a2;
-    if (dw1) dw1[(size_t)j * C + c] += a1;
+    if (gridDim.y == 1) {
+        if (dw2) dw2[(size_t)c * Cr + j] += a2;
+        if (dw1) dw1[(size_t)j * C + c] += a1;
+    } else {
+        if (dw2) atomicAdd(&dw2[(size_t)c * Cr + j], a2);
+        if (dw1) atomicAdd(&dw1[(size_t)j * C + c], a1);
+    }
 }
 
 // B5: du += davg/P + [p == argmax_hw] dmaxp
@@ -478,9 +500,13 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     hipLaunchKernelGGL(cbam_bwd_dpre_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dcg, sv.cg, NC);
     hipLaunchKernelGGL(cbam_bwd_dh_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, dcg, sv.hid, w2, dh, N, C);
     hipLaunchKernelGGL(cbam_bwd_dpool_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dh, w1, davg, dmaxp, N, C);
-    if (dw1 || dw2)
-        hipLaunchKernelGGL(cbam_bwd_mlp_wgrad_kernel, dim3(cdiv((long)C * Cr, 256)), dim3(256), 0, s, dcg, sv.hid, dh, sv.avg,
-                           sv.mx, dw1, dw2, N, C);
+    if (dw1 || dw2) {
+        long chunks = 32768 / ((long)C * Cr);            // aim for >= 32k threads in flight
+        chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
+        const int per = (int)cdiv(N, chunks) < 4 ? 4 : (int)cdiv(N, chunks);
+        hipLaunchKernelGGL(cbam_bwd_mlp_wgrad_kernel, dim3(cdiv((long)C * Cr, 256), cdiv(N, per)), dim3(256), 0, s, dcg, sv.hid,
+                           dh, sv.avg, sv.mx, dw1, dw2, N, C, per);
+    }
     if (defer) { MGVAE_CHECK_LAUNCH(); return MGVAE_OK; }   // the caller's InstanceNorm backward adds the tail
     const long total = (long)NC * P;
     const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);

@@ -42,6 +42,7 @@ struct IgemmP {
     int ktab_stride;    // entries per phase (padded by 16 so a wave can always read its whole row group)
     int w_transposed;   // bwd_data: Wt is [Cy][KH*KW][Cx] (mgvae_weight_transpose) -> lane-contiguous A loads
     unsigned x_bytes, y_bytes, w_bytes;   // extents of X / Y / Wt for the buffer descriptors (< 4 GiB each)
+    int xcd_remap;      // 1: workgroup ids are permuted so that each XCD (own L2) walks a contiguous run of tiles
 };
 
 // Operand loads go through buffer descriptors: a masked element gets the offset 0xFFFFFFFF, which the
@@ -64,25 +65,31 @@ template <int TI, int TJ, bool A_IK, bool B_KJ, int BKc>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                          f32x16 (&acc)[TI][TJ], int wi, int wj, int l31, int h) {
     constexpr int IT = 64 * TI, JT = 64 * TJ, LDPc = BKc + 1;
-#pragma unroll
-    for (int kk = 0; kk < BKc / 2; ++kk) {
+    // register double buffer: the LDS reads of k-step kk+1 are issued before the MFMAs of k-step kk
+    float a[2][TI], b[2][TJ];
+    auto fetch = [&](int kk, int s) {
         const int k = 2 * kk + h;
-        float a[TI], b[TJ];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti) {
             const int i = wi * 32 * TI + ti * 32 + l31;
-            a[ti] = A_IK ? As[i * LDPc + k] : As[k * IT + i];
+            a[s][ti] = A_IK ? As[i * LDPc + k] : As[k * IT + i];
         }
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) {
             const int j = wj * 32 * TJ + tj * 32 + l31;
-            b[tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDPc + k];
+            b[s][tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDPc + k];
         }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BKc / 2; ++kk) {
+        if (kk + 1 < BKc / 2) fetch(kk + 1, (kk + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TJ; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][ti], b[kk & 1][tj], acc[ti][tj], 0, 0, 0);
     }
 }
 
@@ -119,7 +126,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;
-    const int i0 = blockIdx.y * IT, j0 = blockIdx.x * JT;
+    // Hardware deals consecutive workgroup ids round-robin over the 8 XCDs.  Permute the ids so that XCD x
+    // executes the x-th contiguous eighth of the (z, y, x) tile order: the tiles sharing an A row block /
+    // a K split then share one L2 instead of being replicated into all eight.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const unsigned xcd = lin & 7, slot = lin >> 3, per = total >> 3, rem = total & 7;
+        const unsigned l2 = xcd < rem ? xcd * (per + 1) + slot : rem * (per + 1) + (xcd - rem) * per + slot;
+        bx = l2 % gridDim.x;
+        const unsigned t2 = l2 / gridDim.x;
+        by = t2 % gridDim.y; bz = t2 / gridDim.y;
+    }
+    const int i0 = by * IT, j0 = bx * JT;
 
     const int HW = p.H * p.W, P = p.OH * p.OW;
 
@@ -130,12 +150,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     int Ktot = 0, split = 0;
     if constexpr (MODE == MODE_FWD) {
         Itot = p.Cy; Jtot = p.N * P; T = p.KH * p.KW; Ktot = p.Cx * T;
-        split = blockIdx.z;
+        split = (int)bz;
         const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BKc - 1) / BKc * BKc;
         kbeg = split * kc; kend = min(Ktot, kbeg + kc);
     } else if constexpr (MODE == MODE_BWD_DATA) {
-        const int ph = blockIdx.z / p.ksplit;
-        split = blockIdx.z - ph * p.ksplit;
+        const int ph = (int)bz / p.ksplit;
+        split = (int)bz - ph * p.ksplit;
         rh = ph / p.SW; rw = ph - rh * p.SW;
         const int kh0 = (rh + p.PH) % p.SH, kw0 = (rw + p.PW) % p.SW;
         const int nkh = kh0 < p.KH ? (p.KH - kh0 + p.SH - 1) / p.SH : 0;
@@ -155,14 +175,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         if (T == 0) { T = 1; kbeg = 0; kend = 0; }   // no taps: loop never runs
     } else {
         Itot = p.Cy; Jtot = p.Cx * p.KH * p.KW; T = 1;
-        kbeg = blockIdx.z * p.kchunk;
+        kbeg = (int)bz * p.kchunk;
         kend = min(p.N * P, kbeg + p.kchunk);
     }
     const int2* __restrict__ ktab = p.ktab;
     const int* __restrict__ wtab = p.wtab;
     if constexpr (MODE == MODE_BWD_DATA) {
-        ktab += (size_t)(blockIdx.z / p.ksplit) * p.ktab_stride;
-        wtab += (size_t)(blockIdx.z / p.ksplit) * p.ktab_stride;
+        ktab += (size_t)((int)bz / p.ksplit) * p.ktab_stride;
+        wtab += (size_t)((int)bz / p.ksplit) * p.ktab_stride;
     }
 
     // ---------------- loader state ------------------------------------------------------
@@ -387,6 +407,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     }
 }
 
+// Forward of a "thin" convolution (Cx*KH*KW <= 16: the C=1 stems of graph/encodingBlock.py:12-15 and the first
+// layers of graph/bar_discriminator.py): K <= 16 would idle the MFMA and the layer is bound by writing Y.  One
+// thread per output pixel gathers its <= 16 taps once and produces every output channel from them; the weights
+// are wave-uniform (scalar loads), the stores of one channel are contiguous along the lanes.
+template <int JMAX>
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const IgemmP p, int J) {
+    const int P = p.OH * p.OW, HW = p.H * p.W, KK = p.KH * p.KW;
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int oh = i / p.OW, ow = i - oh * p.OW;
+    const int r0 = oh * p.SH - p.PH, c0 = ow * p.SW - p.PW;
+    const float* xb = p.X + ((size_t)n * p.x_ctot + p.x_coff) * HW;
+    float xv[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int jj = j < J ? j : 0;
+        const int cx = jj / KK, t = jj - cx * KK;
+        const int kh = t / p.KW, kw = t - kh * p.KW;
+        const int r = r0 + kh, c = c0 + kw;
+        const bool ok = (j < J) & ((unsigned)r < (unsigned)p.H) & ((unsigned)c < (unsigned)p.W);
+        const float v = xb[ok ? cx * HW + r * p.W + c : 0];
+        xv[j] = ok ? v : 0.f;
+    }
+    float* ob = p.out + (size_t)n * p.y_ctot * P + i;
+    for (int cy = 0; cy < p.Cy; ++cy) {
+        const float* wr = p.Wt + (size_t)cy * J;
+        float v = p.bias ? p.bias[cy] : 0.f;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) v += wr[j < J ? j : 0] * xv[j];   // xv[j] = 0 beyond J
+        ob[(size_t)cy * P] = apply_act(v, p.act, p.slope);
+    }
+}
+
 // zero / activate a channel-sliced tensor [N, C, P] living in a buffer with ctot channels
 __global__ __launch_bounds__(256) void slice_zero_kernel(float* __restrict__ t, long row, long pitch, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -432,6 +486,8 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
     p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0; p.w_transposed = 0;
+    static const int xcd = getenv("MGVAE_XCD") ? atoi(getenv("MGVAE_XCD")) : 0;
+    p.xcd_remap = xcd;
     p.x_bytes = (unsigned)((size_t)d->N * d->x_ctot * d->H * d->W * 4);
     p.y_bytes = (unsigned)((size_t)d->N * d->y_ctot * d->OH * d->OW * 4);
     p.w_bytes = (unsigned)((size_t)d->Cx * d->Cy * d->KH * d->KW * 4);
@@ -753,10 +809,23 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     if (!x || !w || !y) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
     p.X = x; p.Wt = w; p.bias = bias; p.out = y + (size_t)d->y_coff * d->OH * d->OW; p.Y = nullptr;
-    rc = get_ktab(d, MODE_FWD, p);
-    if (rc) return rc;
     hipStream_t s = as_stream(stream);
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW, K = (long)d->Cx * d->KH * d->KW;
+    if (K <= 16 && d->N <= 65535) {
+        const dim3 grid(cdiv((long)d->OH * d->OW, 256), d->N);
+        void* tok = nullptr;
+        g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
+        g_prof_note[5] = d->OH; g_prof_note[6] = d->OW; g_prof_note[7] = d->KH; g_prof_note[8] = d->KW; g_prof_note[9] = d->SH;
+        g_prof_note[10] = d->SW; g_prof_note[11] = grid.x; g_prof_note[12] = grid.y; g_prof_note[13] = 1;
+        mgvae_prof_record_begin(MODE_FWD, 3, 2.0 * I * J * K, stream, &tok);
+        if (K <= 4) hipLaunchKernelGGL(thin_fwd_kernel<4>, grid, dim3(256), 0, s, p, (int)K);
+        else hipLaunchKernelGGL(thin_fwd_kernel<16>, grid, dim3(256), 0, s, p, (int)K);
+        mgvae_prof_record_end(tok, stream);
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
+    rc = get_ktab(d, MODE_FWD, p);
+    if (rc) return rc;
     if (autotune_on() && !is_capturing(s)) {
         const KtabKey key = choice_key(d, MODE_FWD, 0);
         Choice c;
@@ -841,43 +910,70 @@ extern "C" int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx
 }
 
 // Weight gradient of a "thin" convolution (Cx*KH*KW <= 16: the C=1 stems, K1 of SURVEY 2.2): a GEMM
-// with <= 16 columns would waste the MFMA, and it is purely HBM-bound (dY is read once).  One wave
-// per (n, cy) plane keeps the <= 16 partial sums in registers, pixels on the lanes (coalesced dY
-// reads), shuffle-reduces and adds one value per (cy, j) with an atomic.
-template <int JMAX>
-__global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, int J) {
+// with <= 16 columns would waste the MFMA, and it is purely HBM-bound (dY is read once).  Pixels sit
+// on the lanes (coalesced dY reads); a wave walks a strip of one sample's pixels, gathers the <= 16
+// input taps of its pixel ONCE and reuses them for a block of CYB output channels, keeping the
+// CYB x JMAX partial sums in registers.  Shuffle-reduce, combine the four waves through LDS, one
+// atomic per (cy, j) and workgroup.
+template <int CYB, int JMAX>
+__global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, int J, int cpw) {
+    __shared__ float red[4][CYB * JMAX];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int nc = blockIdx.x * 4 + wave;
-    if (nc >= p.N * p.Cy) return;
-    const int n = nc / p.Cy, cy = nc - n * p.Cy;
     const int P = p.OH * p.OW, HW = p.H * p.W, KK = p.KH * p.KW;
-    const float* yp = p.Y + ((size_t)n * p.y_ctot + p.y_coff + cy) * P;
-    const float* xb = p.X + ((size_t)n * p.x_ctot + p.x_coff) * HW;
-    float acc[JMAX];
+    const int n = blockIdx.z, cy0 = blockIdx.y * CYB;
+    const int strip = (blockIdx.x * 4 + wave) * cpw * 64;
+    int joff[JMAX], jdh[JMAX], jdw[JMAX];             // wave-uniform tap constants
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) acc[j] = 0.f;
-    for (int i = lane; i < P; i += 64) {
-        const float g = yp[i];
-        const int oh = i / p.OW, ow = i - oh * p.OW;
+    for (int j = 0; j < JMAX; ++j) {
+        const int jj = j < J ? j : 0;
+        const int cx = jj / KK, t = jj - cx * KK;
+        const int kh = t / p.KW, kw = t - kh * p.KW;
+        jdh[j] = j < J ? kh : -(1 << 28); jdw[j] = kw; joff[j] = cx * HW + kh * p.W + kw;
+    }
+    float acc[CYB][JMAX];
+#pragma unroll
+    for (int c = 0; c < CYB; ++c)
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) acc[c][j] = 0.f;
+    const float* xb = p.X + ((size_t)n * p.x_ctot + p.x_coff) * HW;
+    const float* yb = p.Y + ((size_t)n * p.y_ctot + p.y_coff + cy0) * P;
+    for (int ch = 0; ch < cpw; ++ch) {
+        const int i0 = strip + ch * 64;
+        if (i0 >= P) break;                            // wave-uniform
+        const int i = i0 + lane;
+        const bool pin = i < P;
+        const int ii = pin ? i : 0;
+        const int oh = ii / p.OW, ow = ii - oh * p.OW;
         const int r0 = oh * p.SH - p.PH, c0 = ow * p.SW - p.PW;
+        const int xo = r0 * p.W + c0;
+        float xv[JMAX];
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
-            if (j < J) {
-                const int cx = j / KK, t = j - cx * KK;
-                const int kh = t / p.KW, kw = t - kh * p.KW;
-                const int r = r0 + kh, c = c0 + kw;
-                const bool ok = (unsigned)r < (unsigned)p.H && (unsigned)c < (unsigned)p.W;
-                const float v = xb[ok ? cx * HW + r * p.W + c : 0];
-                acc[j] += ok ? g * v : 0.f;
+            const bool ok = pin & ((unsigned)(r0 + jdh[j]) < (unsigned)p.H) & ((unsigned)(c0 + jdw[j]) < (unsigned)p.W);
+            const float v = xb[ok ? xo + joff[j] : 0];
+            xv[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CYB; ++c) {
+            if (cy0 + c < p.Cy) {                      // wave-uniform
+                const float g = yb[(size_t)c * P + ii];
+#pragma unroll
+                for (int j = 0; j < JMAX; ++j) acc[c][j] += g * xv[j];   // xv is 0 outside the image / strip
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-        if (j < J) {
-            const float sum = wave_sum(acc[j]);
-            if (lane == 0) atomicAdd(&p.out[(size_t)cy * J + j], sum);
+    for (int c = 0; c < CYB; ++c)
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const float sum = wave_sum_lane63(acc[c][j]);
+            if (lane == 63) red[wave][c * JMAX + j] = sum;
         }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CYB * JMAX; t += 256) {
+        const int c = t / JMAX, j = t - c * JMAX;
+        if (j < J && cy0 + c < p.Cy)
+            atomicAdd(&p.out[(size_t)(cy0 + c) * J + j], (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
     }
 }
 
@@ -894,10 +990,15 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
         const double fl = 2.0 * d->Cy * J * (double)d->N * d->OH * d->OW;
         g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
         g_prof_note[5] = d->OH; g_prof_note[6] = d->OW; g_prof_note[7] = d->KH; g_prof_note[8] = d->KW; g_prof_note[9] = d->SH;
-        g_prof_note[10] = d->SW; g_prof_note[11] = cdiv((long)d->N * d->Cy, 4); g_prof_note[12] = 1; g_prof_note[13] = 1;
+        const int P = d->OH * d->OW;
+        int cpw = P / 4096;                               // 64-pixel chunks per wave: >= 16 workgroups per sample
+        cpw = cpw < 1 ? 1 : (cpw > 8 ? 8 : cpw);
+        const int cyb = J <= 4 ? 32 : 8;
+        const dim3 grid(cdiv(P, 256 * cpw), cdiv(d->Cy, cyb), d->N);
+        g_prof_note[10] = d->SW; g_prof_note[11] = grid.x; g_prof_note[12] = grid.y; g_prof_note[13] = grid.z;
         mgvae_prof_record_begin(MODE_BWD_WEIGHT, 3, fl, stream, &tok);
-        if (J <= 4) hipLaunchKernelGGL(thin_bwd_weight_kernel<4>, dim3(cdiv((long)d->N * d->Cy, 4)), dim3(256), 0, as_stream(stream), q, J);
-        else hipLaunchKernelGGL(thin_bwd_weight_kernel<16>, dim3(cdiv((long)d->N * d->Cy, 4)), dim3(256), 0, as_stream(stream), q, J);
+        if (J <= 4) hipLaunchKernelGGL((thin_bwd_weight_kernel<32, 4>), grid, dim3(256), 0, as_stream(stream), q, J, cpw);
+        else hipLaunchKernelGGL((thin_bwd_weight_kernel<8, 16>), grid, dim3(256), 0, as_stream(stream), q, J, cpw);
         mgvae_prof_record_end(tok, stream);
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;

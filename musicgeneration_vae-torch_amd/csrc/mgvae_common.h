@@ -32,6 +32,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the 64 lanes with DPP row shifts / row broadcasts (VALU only -- no LDS round trips like the
+// ds_bpermute behind __shfl_xor): six dependent adds.  The total is valid in LANE 63 only.
+template <int CTRL, int ROW = 0xf, int BANK = 0xf>
+__device__ __forceinline__ float dpp_mov0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW, BANK, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_mov0<0x111>(v);              // row_shr:1
+    v += dpp_mov0<0x112>(v);              // row_shr:2
+    v += dpp_mov0<0x114, 0xf, 0xe>(v);    // row_shr:4
+    v += dpp_mov0<0x118, 0xf, 0xc>(v);    // row_shr:8   -> lane 15 of every row holds the row total
+    v += dpp_mov0<0x142, 0xa>(v);         // row_bcast:15 into rows 1 and 3
+    v += dpp_mov0<0x143, 0xc>(v);         // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -237,15 +237,21 @@ __global__ __launch_bounds__(256) void rowmean_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------ bias gradient
-// db[c] += sum over (n, p) of t[n, coff + c, p]; one workgroup per channel.
+// db[c] += sum over (n, p) of t[n, coff + c, p]; blockIdx.x = channel, blockIdx.y = slice of the samples
+// (enough workgroups to fill the chip even for 32..64 channels), one atomic per workgroup.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ t, int N, int C, int P,
                                                           int ctot, int coff, float* __restrict__ db) {
     __shared__ float part[4];
     const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int n = wave; n < N; n += 4) {          // one wave walks whole (n, c) planes: contiguous, no div
+    for (int n = blockIdx.y * 4 + wave; n < N; n += 4 * gridDim.y) {   // one wave walks whole (n, c) planes
         const float* tp = t + ((size_t)n * ctot + coff + c) * P;
-        for (int i = lane; i < P; i += 64) s += tp[i];
+        if ((P & 3) == 0) {
+            const float4* t4 = reinterpret_cast<const float4*>(tp);
+            for (int i = lane; i < (P >> 2); i += 64) { const float4 v = t4[i]; s += (v.x + v.y) + (v.z + v.w); }
+        } else {
+            for (int i = lane; i < P; i += 64) s += tp[i];
+        }
     }
     s = wave_sum(s);
     if (lane == 0) part[wave] = s;
@@ -435,7 +441,9 @@ extern "C" int mgvae_rowmean_bwd(const float* dout, float* dx, int rows, int L, 
 extern "C" int mgvae_channel_sum_accum(const float* t, int N, int C, int P, int ctot, int coff, float* db,
                                        void* stream) {
     if (!t || !db || N <= 0 || C <= 0 || P <= 0 || coff < 0 || coff + C > ctot) return MGVAE_EINVAL;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, as_stream(stream), t, N, C, P, ctot, coff, db);
+    int ny = cdiv(2048, C);                       // >= 2048 workgroups when the batch allows it
+    ny = ny > cdiv(N, 4) ? cdiv(N, 4) : ny;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, ny), dim3(256), 0, as_stream(stream), t, N, C, P, ctot, coff, db);
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }

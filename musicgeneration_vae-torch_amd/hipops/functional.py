@@ -196,10 +196,17 @@ class _ConvTFn(torch.autograd.Function):
         OW = (wd - 1) * stride[1] - 2 * pad[1] + KW + opad[1]
         y = out if out is not None else torch.empty((N, Co, OH, OW), device=x.device, dtype=torch.float32)
         yct = _pitch(y)
+        k = (KH, KW)
+        if (h == 1 and wd == 1 and tuple(stride) == k and tuple(pad) == (0, 0) and tuple(opad) == (0, 0) and b is None
+                and yct == Co):
+            # a 1x1 map through a non-overlapping transposed conv (the decoder stems, graph/decoder.py:43-46) is the
+            # plain GEMM y[n, (co,kh,kw)] = x[n, ci] . w[ci, (co,kh,kw)]: one launch with the weight read in place,
+            # instead of KH*KW one-tap phases over a transposed copy of the 14 M-element weight
+            Co, OH, OW, k, stride, yct = Co * KH * KW, 1, 1, (1, 1), (1, 1), Co * KH * KW
         # conv geometry: X = y (image side, Cx = Co), Y = x (feature side, Cy = Ci)
-        d = _desc(N, Co, OH, OW, Ci, h, wd, (KH, KW), stride, pad, yct, xct, act, slope)
+        d = _desc(N, Co, OH, OW, Ci, h, wd, k, stride, pad, yct, xct, act, slope)
         _conv_bwd_data(d, x, w, b, y)
-        ctx.geom = (N, Co, OH, OW, Ci, h, wd, (KH, KW), stride, pad, xct, act, slope)
+        ctx.geom = (N, Co, OH, OW, Ci, h, wd, k, stride, pad, xct, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.b = b
         return y
@@ -212,6 +219,10 @@ class _ConvTFn(torch.autograd.Function):
         if act != ACT_NONE:
             dy = _act_bwd(y, dy, act, slope)
         dy, dct = _sliceable(dy)
+        if Co != dy.shape[1]:      # flattened 1x1-input case (see forward): dy [N, co, KH, KW] -> [N, co*KH*KW, 1, 1]
+            if dct != dy.shape[1]:
+                dy = dy.contiguous()
+            dy, dct = dy.view(N, Co, 1, 1), Co
         if w.requires_grad:
             d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
             nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_bwd_weight")
