@@ -128,7 +128,7 @@ int mgvae_batch_norm_bwd(const float* x, const float* gamma, const float* beta, 
  * mode 0: y = cbam(u)                      (graph/cbam.py CBAM.forward)
  * mode 1: y = act(u + cbam(u))             (graph/encodingBlock.py:32,63,122; decoder.py:32,62,103,140,150,213)
  * mode 2: y = act(res + cbam(u))           (graph/encodingBlock.py:94-98)
- * `save` layout (floats): cg[NC] avg[NC] max[NC] argmax_hw[NC](int) hidden[2*N*C/16] s_in[2NP] argmax_c[NP](int)
+ * `save` layout (floats): cg[NC] avg[NC] max[NC] argmax_hw[NC](int) hidden[2*N*C/16, padded to a multiple of 4] s_in[2NP] argmax_c[NP](int)
  * sg[NP]; bwd `scratch`: dt[NP] ds_in[2NP] dcg[NC] davg[NC] dmaxp[NC] dh[2*N*C/16].
  * parts | 4: forward -- avg/max/argmax were already written into `save` by mgvae_instance_norm_fwd;
  * backward -- skip the final "du += davg/P + [p==argmax] dmaxp" pass: the caller's

@@ -19,14 +19,14 @@ struct CbamSave {   // carve-up of the `save` workspace (floats)
     int *amax_hw, *amax_c;
 };
 static __host__ __device__ inline size_t cbam_save_floats(int N, int C, int P) {
-    return (size_t)4 * N * C + (size_t)2 * N * (C / 16) + (size_t)4 * N * P;
+    return (size_t)4 * N * C + (((size_t)2 * N * (C / 16) + 3) & ~(size_t)3) + (size_t)4 * N * P;   // hid padded: 16-B aligned maps
 }
 static inline CbamSave carve(float* s, int N, int C, int P) {
     CbamSave r;
     const size_t nc = (size_t)N * C, np = (size_t)N * P;
     r.cg = s; r.avg = s + nc; r.mx = s + 2 * nc; r.amax_hw = reinterpret_cast<int*>(s + 3 * nc);
     r.hid = s + 4 * nc;
-    float* q = r.hid + (size_t)2 * N * (C / 16);
+    float* q = r.hid + (((size_t)2 * N * (C / 16) + 3) & ~(size_t)3);
     r.s_in = q; r.amax_c = reinterpret_cast<int*>(q + 2 * np); r.sg = q + 3 * np;
     return r;
 }
@@ -189,6 +189,30 @@ __global__ __launch_bounds__(256) void cbam_apply_kernel(const float* __restrict
     }
 }
 
+// float4 variant (P % 4 == 0: four pixels of one plane per thread)
+__global__ __launch_bounds__(256) void cbam_apply_vec_kernel(const float* __restrict__ u, const float* __restrict__ res,
+                                                             const float* __restrict__ cg, const float* __restrict__ sg,
+                                                             float* __restrict__ y, int N, int C, int P, int y_ctot,
+                                                             int y_coff, int mode, int act, float slope) {
+    const long total4 = (long)N * C * P / 4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * 256) {
+        const long i = i4 * 4;
+        const int nc = (int)(i / P), pp = (int)(i - (long)nc * P);
+        const int n = nc / C, c = nc - n * C;
+        const float4 uu = *reinterpret_cast<const float4*>(u + i);
+        const float4 sv = *reinterpret_cast<const float4*>(sg + (size_t)n * P + pp);
+        const float g = cg[nc];
+        float4 o = make_float4((uu.x * g) * sv.x, (uu.y * g) * sv.y, (uu.z * g) * sv.z, (uu.w * g) * sv.w);
+        if (mode != 0) {
+            float4 b = uu;
+            if (mode == 2) b = *reinterpret_cast<const float4*>(res + i);
+            o.x = apply_act(b.x + o.x, act, slope); o.y = apply_act(b.y + o.y, act, slope);
+            o.z = apply_act(b.z + o.z, act, slope); o.w = apply_act(b.w + o.w, act, slope);
+        }
+        *reinterpret_cast<float4*>(y + ((size_t)n * y_ctot + y_coff + c) * P + pp) = o;
+    }
+}
+
 // ================================================================ backward
 // B1: dt[n,p] = (sum_c g * u * cg) * sg * (1 - sg),  g = dy * act'(y)
 template <int PXB>
@@ -304,6 +328,52 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_kernel(
         acc += dv * up[i];
         du[(size_t)nc * P + i] = dv * g_c + (mode == 1 ? g : 0.f);
         if (mode == 2) dres[(size_t)nc * P + i] = g;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) dcg[nc] = acc;
+}
+
+// float4 variant of B3 (P % 4 == 0)
+__global__ __launch_bounds__(256) void cbam_bwd_channel_vec_kernel(
+    const float* __restrict__ u, const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ cg,
+    const float* __restrict__ sg, const float* __restrict__ ds_in, const int* __restrict__ amax_c,
+    float* __restrict__ du, float* __restrict__ dres, float* __restrict__ dcg, int N, int C, int P, int y_ctot,
+    int y_coff, int mode, int act, float slope) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nc = blockIdx.x * 4 + wave;
+    if (nc >= N * C) return;
+    const int n = nc / C, c = nc - n * C;
+    const float4* up = reinterpret_cast<const float4*>(u + (size_t)nc * P);
+    const float4* yp = reinterpret_cast<const float4*>(y + ((size_t)n * y_ctot + y_coff + c) * P);
+    const float4* dyp = reinterpret_cast<const float4*>(dy + ((size_t)n * y_ctot + y_coff + c) * P);
+    const float4* sgp = reinterpret_cast<const float4*>(sg + (size_t)n * P);
+    const float4* dmean = reinterpret_cast<const float4*>(ds_in + (size_t)n * 2 * P);
+    const float4* dmax = reinterpret_cast<const float4*>(ds_in + (size_t)n * 2 * P + P);
+    const int4* amp = reinterpret_cast<const int4*>(amax_c + (size_t)n * P);
+    float4* dup = reinterpret_cast<float4*>(du + (size_t)nc * P);
+    float4* drp = mode == 2 ? reinterpret_cast<float4*>(dres + (size_t)nc * P) : nullptr;
+    const float g_c = cg[nc], invC = 1.f / (float)C;
+    float acc = 0.f;
+    for (int i = lane; i < (P >> 2); i += 64) {
+        float4 g = dyp[i];
+        if (mode != 0) {
+            const float4 yy = yp[i];
+            g.x *= act_grad_from_out(yy.x, act, slope); g.y *= act_grad_from_out(yy.y, act, slope);
+            g.z *= act_grad_from_out(yy.z, act, slope); g.w *= act_grad_from_out(yy.w, act, slope);
+        }
+        const float4 s4 = sgp[i], dm = dmean[i], dx = dmax[i], uu = up[i];
+        const int4 am = amp[i];
+        float4 dv = make_float4(g.x * s4.x + dm.x * invC, g.y * s4.y + dm.y * invC, g.z * s4.z + dm.z * invC,
+                                g.w * s4.w + dm.w * invC);
+        if (am.x == c) dv.x += dx.x;
+        if (am.y == c) dv.y += dx.y;
+        if (am.z == c) dv.z += dx.z;
+        if (am.w == c) dv.w += dx.w;
+        acc += (dv.x * uu.x + dv.y * uu.y) + (dv.z * uu.z + dv.w * uu.w);
+        const float k = mode == 1 ? 1.f : 0.f;
+        dup[i] = make_float4(dv.x * g_c + k * g.x, dv.y * g_c + k * g.y, dv.z * g_c + k * g.z, dv.w * g_c + k * g.w);
+        if (mode == 2) drp[i] = g;
     }
     acc = wave_sum(acc);
     if (lane == 0) dcg[nc] = acc;
@@ -456,6 +526,10 @@ extern "C" int mgvae_cbam_fwd(const float* u, const float* res, const float* w1,
     }
     const long total = (long)NC * P;
     const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    if ((P & 3) == 0)
+        hipLaunchKernelGGL(cbam_apply_vec_kernel, dim3(blocks), dim3(256), 0, s, u, res, sv.cg, sv.sg, y, N, C, P, y_ctot, y_coff,
+                           mode, act, slope);
+    else
     hipLaunchKernelGGL(cbam_apply_kernel, dim3(blocks), dim3(256), 0, s, u, res, sv.cg, sv.sg, y, N, C, P, y_ctot,
                        y_coff, mode, act, slope);
     MGVAE_CHECK_LAUNCH();
@@ -494,8 +568,12 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     hipLaunchKernelGGL(cbam_bwd_sgate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, dt, sv.s_in, wsp, ds_in,
                        dwsp, N, H, W);
     }
-    hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
-                       sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
+    if ((P & 3) == 0)
+        hipLaunchKernelGGL(cbam_bwd_channel_vec_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
+                           sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
+    else
+        hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
+                           sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
     if (!chan) { MGVAE_CHECK_LAUNCH(); return MGVAE_OK; }   // no channel gate: du is complete
     hipLaunchKernelGGL(cbam_bwd_dpre_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dcg, sv.cg, NC);
     hipLaunchKernelGGL(cbam_bwd_dh_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, dcg, sv.hid, w2, dh, N, C);

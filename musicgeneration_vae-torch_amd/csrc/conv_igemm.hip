@@ -410,10 +410,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 // Forward of a "thin" convolution (Cx*KH*KW <= 16: the C=1 stems of graph/encodingBlock.py:12-15 and the first
 // layers of graph/bar_discriminator.py): K <= 16 would idle the MFMA and the layer is bound by writing Y.  One
 // thread per output pixel gathers its <= 16 taps once and produces every output channel from them; the weights
-// are wave-uniform (scalar loads), the stores of one channel are contiguous along the lanes.
-template <int JMAX>
+// (and bias) sit in LDS and are read as broadcasts, the stores of one channel are contiguous along the lanes.
+constexpr int THIN_W_MAX = 4096;          // Cy * J floats that fit the LDS weight stage
+template <int JMAX, int ACT>
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const IgemmP p, int J) {
+    __shared__ float wsh[THIN_W_MAX];
+    __shared__ float bsh[THIN_W_MAX / 4];
     const int P = p.OH * p.OW, HW = p.H * p.W, KK = p.KH * p.KW;
+    for (int t = threadIdx.x; t < p.Cy * J; t += 256) wsh[t] = p.Wt[t];
+    for (int t = threadIdx.x; t < p.Cy; t += 256) bsh[t] = p.bias ? p.bias[t] : 0.f;
+    __syncthreads();
     const int n = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -432,12 +438,13 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const IgemmP p, int J) {
         xv[j] = ok ? v : 0.f;
     }
     float* ob = p.out + (size_t)n * p.y_ctot * P + i;
+#pragma unroll 8
     for (int cy = 0; cy < p.Cy; ++cy) {
-        const float* wr = p.Wt + (size_t)cy * J;
-        float v = p.bias ? p.bias[cy] : 0.f;
+        const float* wr = wsh + cy * J;
+        float v = bsh[cy];
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) v += wr[j < J ? j : 0] * xv[j];   // xv[j] = 0 beyond J
-        ob[(size_t)cy * P] = apply_act(v, p.act, p.slope);
+        ob[(size_t)cy * P] = apply_act(v, ACT, p.slope);
     }
 }
 
@@ -811,15 +818,22 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     p.X = x; p.Wt = w; p.bias = bias; p.out = y + (size_t)d->y_coff * d->OH * d->OW; p.Y = nullptr;
     hipStream_t s = as_stream(stream);
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW, K = (long)d->Cx * d->KH * d->KW;
-    if (K <= 16 && d->N <= 65535) {
+    if (K <= 16 && d->N <= 65535 && I * K <= THIN_W_MAX && I <= THIN_W_MAX / 4) {
         const dim3 grid(cdiv((long)d->OH * d->OW, 256), d->N);
         void* tok = nullptr;
         g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
         g_prof_note[5] = d->OH; g_prof_note[6] = d->OW; g_prof_note[7] = d->KH; g_prof_note[8] = d->KW; g_prof_note[9] = d->SH;
         g_prof_note[10] = d->SW; g_prof_note[11] = grid.x; g_prof_note[12] = grid.y; g_prof_note[13] = 1;
         mgvae_prof_record_begin(MODE_FWD, 3, 2.0 * I * J * K, stream, &tok);
-        if (K <= 4) hipLaunchKernelGGL(thin_fwd_kernel<4>, grid, dim3(256), 0, s, p, (int)K);
-        else hipLaunchKernelGGL(thin_fwd_kernel<16>, grid, dim3(256), 0, s, p, (int)K);
+#define MGVAE_THIN_FWD(JM)                                                                                              \
+    switch (d->act) {                                                                                                   \
+        case MGVAE_ACT_RELU: hipLaunchKernelGGL((thin_fwd_kernel<JM, MGVAE_ACT_RELU>), grid, dim3(256), 0, s, p, (int)K); break;       \
+        case MGVAE_ACT_LEAKY: hipLaunchKernelGGL((thin_fwd_kernel<JM, MGVAE_ACT_LEAKY>), grid, dim3(256), 0, s, p, (int)K); break;     \
+        case MGVAE_ACT_SIGMOID: hipLaunchKernelGGL((thin_fwd_kernel<JM, MGVAE_ACT_SIGMOID>), grid, dim3(256), 0, s, p, (int)K); break; \
+        default: hipLaunchKernelGGL((thin_fwd_kernel<JM, MGVAE_ACT_NONE>), grid, dim3(256), 0, s, p, (int)K); break;                   \
+    }
+        if (K <= 4) { MGVAE_THIN_FWD(4) } else { MGVAE_THIN_FWD(16) }
+#undef MGVAE_THIN_FWD
         mgvae_prof_record_end(tok, stream);
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
@@ -911,17 +925,19 @@ extern "C" int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx
 
 // Weight gradient of a "thin" convolution (Cx*KH*KW <= 16: the C=1 stems, K1 of SURVEY 2.2): a GEMM
 // with <= 16 columns would waste the MFMA, and it is purely HBM-bound (dY is read once).  Pixels sit
-// on the lanes (coalesced dY reads); a wave walks a strip of one sample's pixels, gathers the <= 16
+// on the lanes (coalesced dY reads); a wave takes 64-pixel chunks of one sample, gathers the <= 16
 // input taps of its pixel ONCE and reuses them for a block of CYB output channels, keeping the
-// CYB x JMAX partial sums in registers.  Shuffle-reduce, combine the four waves through LDS, one
-// atomic per (cy, j) and workgroup.
+// CYB x JMAX partial sums in registers ACROSS chunks (persistent waves: every workgroup ends with
+// CYB*JMAX atomics onto the same few cache lines, so the grid is capped at about two workgroups per
+// CU).  DPP-reduce over the lanes, combine the four waves through LDS.
 template <int CYB, int JMAX>
-__global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, int J, int cpw) {
+__global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, int J) {
     __shared__ float red[4][CYB * JMAX];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int P = p.OH * p.OW, HW = p.H * p.W, KK = p.KH * p.KW;
-    const int n = blockIdx.z, cy0 = blockIdx.y * CYB;
-    const int strip = (blockIdx.x * 4 + wave) * cpw * 64;
+    const int cy0 = blockIdx.y * CYB;
+    const int cps = (P + 63) >> 6;                     // chunks per sample
+    const int total = p.N * cps;
     int joff[JMAX], jdh[JMAX], jdw[JMAX];             // wave-uniform tap constants
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
@@ -935,17 +951,16 @@ __global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, in
     for (int c = 0; c < CYB; ++c)
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) acc[c][j] = 0.f;
-    const float* xb = p.X + ((size_t)n * p.x_ctot + p.x_coff) * HW;
-    const float* yb = p.Y + ((size_t)n * p.y_ctot + p.y_coff + cy0) * P;
-    for (int ch = 0; ch < cpw; ++ch) {
-        const int i0 = strip + ch * 64;
-        if (i0 >= P) break;                            // wave-uniform
-        const int i = i0 + lane;
+    for (int ch = blockIdx.x * 4 + wave; ch < total; ch += gridDim.x * 4) {
+        const int n = ch / cps;                        // wave-uniform
+        const int i = (ch - n * cps) * 64 + lane;
         const bool pin = i < P;
         const int ii = pin ? i : 0;
         const int oh = ii / p.OW, ow = ii - oh * p.OW;
         const int r0 = oh * p.SH - p.PH, c0 = ow * p.SW - p.PW;
         const int xo = r0 * p.W + c0;
+        const float* xb = p.X + ((size_t)n * p.x_ctot + p.x_coff) * HW;
+        const float* yb = p.Y + ((size_t)n * p.y_ctot + p.y_coff + cy0) * P;
         float xv[JMAX];
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
@@ -953,14 +968,15 @@ __global__ __launch_bounds__(256) void thin_bwd_weight_kernel(const IgemmP p, in
             const float v = xb[ok ? xo + joff[j] : 0];
             xv[j] = ok ? v : 0.f;
         }
+        // no branch on the channel bound: a clamped (valid) address keeps all CYB loads in flight together; the
+        // sums of channels >= Cy are garbage that is never written
+        float g[CYB];
 #pragma unroll
-        for (int c = 0; c < CYB; ++c) {
-            if (cy0 + c < p.Cy) {                      // wave-uniform
-                const float g = yb[(size_t)c * P + ii];
+        for (int c = 0; c < CYB; ++c) g[c] = yb[(size_t)(cy0 + c < p.Cy ? c : 0) * P + ii];
 #pragma unroll
-                for (int j = 0; j < JMAX; ++j) acc[c][j] += g * xv[j];   // xv is 0 outside the image / strip
-            }
-        }
+        for (int c = 0; c < CYB; ++c)
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) acc[c][j] += g[c] * xv[j];   // xv is 0 outside the image / sample
     }
 #pragma unroll
     for (int c = 0; c < CYB; ++c)
@@ -991,14 +1007,17 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
         g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
         g_prof_note[5] = d->OH; g_prof_note[6] = d->OW; g_prof_note[7] = d->KH; g_prof_note[8] = d->KW; g_prof_note[9] = d->SH;
         const int P = d->OH * d->OW;
-        int cpw = P / 4096;                               // 64-pixel chunks per wave: >= 16 workgroups per sample
-        cpw = cpw < 1 ? 1 : (cpw > 8 ? 8 : cpw);
+        const long chunks = (long)d->N * cdiv(P, 64);
         const int cyb = J <= 4 ? 32 : 8;
-        const dim3 grid(cdiv(P, 256 * cpw), cdiv(d->Cy, cyb), d->N);
+        const int ycount = cdiv(d->Cy, cyb);
+        long gx = cdiv(chunks, 4);
+        const long cap = 2 * g_cus / ycount > 32 ? 2 * g_cus / ycount : 32;   // ~two workgroups per CU (see kernel)
+        if (gx > cap) gx = cap;
+        const dim3 grid((unsigned)gx, ycount, 1);
         g_prof_note[10] = d->SW; g_prof_note[11] = grid.x; g_prof_note[12] = grid.y; g_prof_note[13] = grid.z;
         mgvae_prof_record_begin(MODE_BWD_WEIGHT, 3, fl, stream, &tok);
-        if (J <= 4) hipLaunchKernelGGL((thin_bwd_weight_kernel<32, 4>), grid, dim3(256), 0, as_stream(stream), q, J, cpw);
-        else hipLaunchKernelGGL((thin_bwd_weight_kernel<8, 16>), grid, dim3(256), 0, as_stream(stream), q, J, cpw);
+        if (J <= 4) hipLaunchKernelGGL((thin_bwd_weight_kernel<32, 4>), grid, dim3(256), 0, as_stream(stream), q, J);
+        else hipLaunchKernelGGL((thin_bwd_weight_kernel<8, 16>), grid, dim3(256), 0, as_stream(stream), q, J);
         mgvae_prof_record_end(tok, stream);
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
