@@ -4,6 +4,7 @@ The reference's Refiner cannot run as committed (its ``layer2`` expects 1 input 
 but receives 2: SURVEY defect D2), so calling ``Model.forward`` there raises.  This build
 keeps the signature and return structure; the refiner stage is an explicit, default-off
 option until its parity can be pinned."""
+import torch
 from torch import nn
 
 from graph.decoder import Decoder
@@ -24,15 +25,25 @@ class Model(nn.Module):
             self.refiner = Refiner()          # D2-fixed (layer2 takes 2 channels); parity unpinned
         self.apply(weights_init)
 
+    def encode_pair(self, note, pre_note):
+        """``encoder(note), encoder(pre_note)`` (graph/model.py:27,29) as ONE pass over the 2B stacked bars: the encoder
+        has no cross-sample op (InstanceNorm and CBAM pool per sample), so stacking is exact, halves the launches and
+        doubles the pixel axis of the small-map GEMMs."""
+        if getattr(self.encoder, "variational", False) or note.shape != pre_note.shape:
+            return self.encoder(note), self.encoder(pre_note)
+        zz = self.encoder(torch.cat([note, pre_note], 0))
+        b = note.shape[0]
+        return zz[:b], zz[b:]
+
     def forward(self, note, pre_note, phrase, position, is_train=True):
         phrase_feature = self.phrase_encoder(phrase)
-        pre_z = self.encoder(pre_note)
         if is_train:
-            z = self.encoder(note)
+            z, pre_z = self.encode_pair(note, pre_note)
             gen = self.decoder(z, pre_z, phrase_feature, position)
             if self.use_refiner:
                 gen = self.refiner(gen)
             return gen, z, pre_z, phrase_feature
         # sampling: ``note`` is a latent [B,1152]
+        pre_z = self.encoder(pre_note)
         gen = self.decoder(note, pre_z, phrase_feature, position)
         return self.refiner(gen) if self.use_refiner else gen

@@ -17,14 +17,23 @@ class Model(nn.Module):
         self.phrase_encoder = PhraseModel([64, 128, 256, 512, 1024])
         self.apply(weights_init)
 
+    def encode_pair(self, note, pre_note):
+        """both bar-encoder passes of graph/model_with_gan.py:22,24 as one pass over the 2B stacked bars
+        (exact: no cross-sample op in the encoder)"""
+        if getattr(self.encoder, "variational", False) or note.shape != pre_note.shape:
+            return self.encoder(note), self.encoder(pre_note)
+        zz = self.encoder(torch.cat([note, pre_note], 0))
+        b = note.shape[0]
+        return zz[:b], zz[b:]
+
     def forward(self, note, pre_note, phrase, position, is_note=True):
         phrase_feature = self.phrase_encoder(phrase)
-        pre_z = self.encoder(pre_note)
         if is_note:
-            z = self.encoder(note)
+            z, pre_z = self.encode_pair(note, pre_note)
             gen = self.decoder(z, pre_z, phrase_feature, position)
             fake = torch.gt(gen.detach(), 0.3).float()
             return gen, z, pre_z, phrase_feature, self.encoder(fake)
+        pre_z = self.encoder(pre_note)
         gen = self.decoder(note, pre_z, phrase_feature, position)
         fake = torch.gt(gen.detach(), 0.3).float()
         return gen, self.encoder(fake)
