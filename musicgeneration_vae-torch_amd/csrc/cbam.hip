@@ -379,6 +379,47 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_vec_kernel(
     if (lane == 0) dcg[nc] = acc;
 }
 
+// small planes (P <= G*E): G lanes per (n, c) plane, several planes per wave (see norm.hip, small planes)
+template <int G, int E>
+__global__ __launch_bounds__(256) void cbam_bwd_channel_mini_kernel(
+    const float* __restrict__ u, const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ cg,
+    const float* __restrict__ sg, const float* __restrict__ ds_in, const int* __restrict__ amax_c,
+    float* __restrict__ du, float* __restrict__ dres, float* __restrict__ dcg, int N, int C, int P, int y_ctot,
+    int y_coff, int mode, int act, float slope) {
+    const int l = threadIdx.x % G;
+    const int plane = (blockIdx.x * 256 + threadIdx.x) / G;
+    const bool live = plane < N * C;
+    const int nc = live ? plane : N * C - 1;
+    const int n = nc / C, c = nc - n * C;
+    const float* up = u + (size_t)nc * P;
+    const float* yp = y + ((size_t)n * y_ctot + y_coff + c) * P;
+    const float* dyp = dy + ((size_t)n * y_ctot + y_coff + c) * P;
+    const float* sgp = sg + (size_t)n * P;
+    const float* dmean = ds_in + (size_t)n * 2 * P;
+    const float* dmax = dmean + P;
+    const int* amp = amax_c + (size_t)n * P;
+    const float g_c = cg[nc], invC = 1.f / (float)C;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = l + G * k;
+        if (i < P) {
+            float g = dyp[i];
+            if (mode != 0) g *= act_grad_from_out(yp[i], act, slope);
+            float dv = g * sgp[i] + dmean[i] * invC;
+            if (amp[i] == c) dv += dmax[i];
+            acc += dv * up[i];
+            if (live) {
+                du[(size_t)nc * P + i] = dv * g_c + (mode == 1 ? g : 0.f);
+                if (mode == 2) dres[(size_t)nc * P + i] = g;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+    if (l == 0 && live) dcg[nc] = acc;
+}
+
 // B4a: MLP backward, fully parallel: (1) dpre[n,c] = dcg * cg * (1 - cg) in place; (2) one wave per
 // (n, j): dh = W2[:,j] . dpre[n,:], masked by the two ReLUs; (3) one thread per (n, c): davg / dmaxp.
 __global__ __launch_bounds__(256) void cbam_bwd_dpre_kernel(float* __restrict__ dcg, const float* __restrict__ cg, int total) {
@@ -568,7 +609,13 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     hipLaunchKernelGGL(cbam_bwd_sgate_kernel, dim3(cdiv((long)N * P, 256)), dim3(256), 0, s, dt, sv.s_in, wsp, ds_in,
                        dwsp, N, H, W);
     }
-    if ((P & 3) == 0)
+    if (P <= 24)
+        hipLaunchKernelGGL((cbam_bwd_channel_mini_kernel<8, 3>), dim3(cdiv((long)NC * 8, 256)), dim3(256), 0, s, u, y, dy, sv.cg,
+                           sv.sg, ds_in, sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
+    else if (P <= 96)
+        hipLaunchKernelGGL((cbam_bwd_channel_mini_kernel<16, 6>), dim3(cdiv((long)NC * 16, 256)), dim3(256), 0, s, u, y, dy, sv.cg,
+                           sv.sg, ds_in, sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
+    else if ((P & 3) == 0)
         hipLaunchKernelGGL(cbam_bwd_channel_vec_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
                            sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
     else

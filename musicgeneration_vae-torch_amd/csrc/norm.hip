@@ -93,6 +93,109 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------ small planes
+// P <= G*E (the 3x2 ... 12x8 maps of the deep encoder / first decoder blocks): a whole wave per plane would leave
+// most lanes idle, so G = 8 or 16 lanes share a plane (8 or 4 planes per wave), the plane lives in E registers per
+// lane and the reductions are xor-shuffles inside the lane group.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+template <int G, int E>
+__global__ __launch_bounds__(256) void instance_norm_fwd_mini_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ stats, int NC, int C, int P, int y_ctot, int y_coff,
+    float eps, int act, float slope, float* __restrict__ pavg, float* __restrict__ pmax, int* __restrict__ pidx) {
+    const int l = threadIdx.x % G;
+    const int plane = (blockIdx.x * 256 + threadIdx.x) / G;
+    const bool live = plane < NC;
+    const int nc = live ? plane : NC - 1;
+    const int n = nc / C, c = nc - n * C;
+    const float* xp = x + (size_t)nc * P;
+    float v[E];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) { const int i = l + G * k; v[k] = i < P ? xp[i] : 0.f; s += v[k]; }
+    const float mean = group_sum<G>(s) / (float)P;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) { const float d = (l + G * k) < P ? v[k] - mean : 0.f; q += d * d; }
+    const float rstd = 1.0f / sqrtf(group_sum<G>(q) / (float)P + eps);
+    if (l == 0 && live) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
+    const float g = gamma[c], b = beta[c];
+    float* yp = y + ((size_t)n * y_ctot + y_coff + c) * P;
+    float ps = 0.f, pm = -INFINITY; int pi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = l + G * k;
+        if (i < P) {
+            const float o = apply_act((v[k] - mean) * rstd * g + b, act, slope);
+            if (live) yp[i] = o;
+            ps += o;
+            if (o > pm) { pm = o; pi = i; }
+        }
+    }
+    if (pavg) {
+        ps = group_sum<G>(ps);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const float om = __shfl_xor(pm, o, G);
+            const int oi = __shfl_xor(pi, o, G);
+            if (om > pm || (om == pm && oi < pi)) { pm = om; pi = oi; }
+        }
+        if (l == 0 && live) { pavg[nc] = ps / (float)P; pmax[nc] = pm; pidx[nc] = pi; }
+    }
+}
+
+template <int G, int E>
+__global__ __launch_bounds__(256) void instance_norm_bwd_mini_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stats, const float* __restrict__ dy, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int C, int P, int dy_ctot, int dy_coff,
+    int act, float slope, const float* __restrict__ addc, const float* __restrict__ addp, const int* __restrict__ addi) {
+    const int l = threadIdx.x % G;
+    const int plane = (blockIdx.x * 256 + threadIdx.x) / G;
+    const bool live = plane < NC;
+    const int nc = live ? plane : NC - 1;
+    const int n = nc / C, c = nc - n * C;
+    const float* xp = x + (size_t)nc * P;
+    const float* dyp = dy + ((size_t)n * dy_ctot + dy_coff + c) * P;
+    const float mean = stats[2 * nc], rstd = stats[2 * nc + 1];
+    const float g = gamma[c], b = beta[c];
+    const float ac = addc ? addc[nc] / (float)P : 0.f, ap = addc ? addp[nc] : 0.f;
+    const int ai = addc ? addi[nc] : -1;
+    float xh[E], gr[E];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = l + G * k;
+        const bool in = i < P;
+        xh[k] = in ? (xp[i] - mean) * rstd : 0.f;
+        float t = in ? dyp[i] + ac + (i == ai ? ap : 0.f) : 0.f;
+        if (act != MGVAE_ACT_NONE) {
+            const float u = xh[k] * g + b;
+            t *= (u > 0.f) ? 1.f : (act == MGVAE_ACT_LEAKY ? slope : 0.f);
+        }
+        gr[k] = t;
+        s1 += t; s2 += t * xh[k];
+    }
+    s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
+    if (l == 0 && live) {
+        if (dgamma) atomicAdd(&dgamma[c], s2);
+        if (dbeta) atomicAdd(&dbeta[c], s1);
+    }
+    const float m1 = s1 / (float)P, m2 = s2 / (float)P, kk = g * rstd;
+    float* dxp = dx + (size_t)nc * P;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = l + G * k;
+        if (i < P && live) dxp[i] = kk * (gr[k] - m1 - xh[k] * m2);
+    }
+}
+
 // ------------------------------------------------------------------------ register-resident variants
 // P % 4 == 0 and P <= 256*NV: the whole plane lives in NV float4 registers per lane, so x (and dy)
 // are read from HBM exactly once, as 16-byte lane-contiguous loads.
@@ -382,6 +485,13 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
     const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
 #define MGVAE_INF(NV) hipLaunchKernelGGL(instance_norm_fwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
                                          gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx)
+    if (P <= 24) {
+        hipLaunchKernelGGL((instance_norm_fwd_mini_kernel<8, 3>), dim3(cdiv((long)NC * 8, 256)), dim3(256), 0, as_stream(stream), x,
+                           gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx);
+    } else if (P <= 96) {
+        hipLaunchKernelGGL((instance_norm_fwd_mini_kernel<16, 6>), dim3(cdiv((long)NC * 16, 256)), dim3(256), 0, as_stream(stream), x,
+                           gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx);
+    } else
     switch (al ? pick_nv(P) : 0) {
         case 1: MGVAE_INF(1); break;
         case 2: MGVAE_INF(2); break;
@@ -408,6 +518,15 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
 #define MGVAE_INB(NV) hipLaunchKernelGGL(instance_norm_bwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
                                          gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const, \
                                          add_point, add_index)
+    if (P <= 24) {
+        hipLaunchKernelGGL((instance_norm_bwd_mini_kernel<8, 3>), dim3(cdiv((long)NC * 8, 256)), dim3(256), 0, as_stream(stream), x,
+                           gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const,
+                           add_point, add_index);
+    } else if (P <= 96) {
+        hipLaunchKernelGGL((instance_norm_bwd_mini_kernel<16, 6>), dim3(cdiv((long)NC * 16, 256)), dim3(256), 0, as_stream(stream), x,
+                           gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const,
+                           add_point, add_index);
+    } else
     switch (al ? pick_nv(P) : 0) {
         case 1: MGVAE_INB(1); break;
         case 2: MGVAE_INB(2); break;

@@ -10,6 +10,15 @@ from . import dist as hdist
 from .flat import FlatParams
 
 
+def _stacked(a, b):
+    """the [2B, D] tensor that ``a`` and ``b`` are the two halves of (graph.model.Model.encode_pair), else None"""
+    base = a._base
+    if (base is None or base is not b._base or a.shape != b.shape or base.numel() != 2 * a.numel()
+            or a.data_ptr() != base.data_ptr() or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size()):
+        return None
+    return base.view(2 * a.shape[0], -1)
+
+
 class PretrainStep:
     def __init__(self, generator, z_disc_bar, z_disc_phrase, loss_gen, loss_d, lr=0.002, bucket_elems=16 * 1024 * 1024):
         self.gen, self.zb, self.zp = generator, z_disc_bar, z_disc_phrase
@@ -45,7 +54,11 @@ class PretrainStep:
         gen, z, pre_z, pf = self.gen(note, pre_note, phrase, position)
         self._arm_overlap((z, pre_z, pf))
         loss = DLoss.constant(self.zp(pf).view(-1), 1.0)
-        loss = loss + DLoss.constant(self.zb(z).view(-1), 1.0) + DLoss.constant(self.zb(pre_z).view(-1), 1.0)
+        zz = _stacked(z, pre_z)
+        if zz is not None:      # one discriminator pass over both latents: mean over 2B, twice = the two means over B
+            loss = loss + 2.0 * DLoss.constant(self.zb(zz).view(-1), 1.0)
+        else:
+            loss = loss + DLoss.constant(self.zb(z).view(-1), 1.0) + DLoss.constant(self.zb(pre_z).view(-1), 1.0)
         loss = loss + self.loss_gen(gen, note, is_pretraining)
         loss.backward()
         self.reducer.reduce_rest()

@@ -204,7 +204,8 @@ def test_conv_transpose2d_fwd_bwd(g, conv_path):
 
 
 # ---------------------------------------------------------------------- norm / cbam
-@pytest.mark.parametrize("shape", [(3, 32, 48, 30), (2, 1024, 3, 2), (2, 512, 12, 7), (2, 64, 96, 60), (1, 16, 1, 6)])
+@pytest.mark.parametrize("shape", [(3, 32, 48, 30), (2, 1024, 3, 2), (2, 512, 12, 7), (2, 64, 96, 60), (1, 16, 1, 6),
+                                   (3, 20, 4, 6), (1, 7, 12, 8), (5, 3, 5, 5)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_instance_norm(shape, act):
     x = torch.randn(shape) * 3 + 1
@@ -253,7 +254,7 @@ def test_cbam(shape, mode, act):
 
 
 @pytest.mark.parametrize("shape", [(3, 32, 48, 30), (2, 1024, 6, 3), (2, 128, 24, 15), (2, 64, 12, 7), (2, 64, 96, 61),
-                                   (1, 256, 12, 8)])
+                                   (1, 256, 12, 8), (3, 32, 6, 4), (5, 16, 3, 2)])
 @pytest.mark.parametrize("mode,act", [(1, 1), (1, 2), (2, 1)])
 def test_norm_cbam_fused(shape, mode, act):
     """InstanceNorm -> CBAM -> residual -> activation as one node (pooling fused into the norm
