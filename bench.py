@@ -96,6 +96,23 @@ def cpu_baseline(batch=4, steps=2):
                       % (steps, batch, torch.__version__)}
 
 
+def pmc_record(kernel):
+    """HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) and the
+    MFMA-busy share of ``kernel`` from the newest committed PMC summary (profiles/rN?_pmc_summary.json, written by
+    tools/pmc_collect.sh + tools/pmc_summary.py: counters cannot be read from inside this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1])).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if rec:
+        rec = dict(rec, source="profiles/" + os.path.basename(files[-1]))
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,8 +209,12 @@ def main():
         tot_ms = sum(f["ms"] for f in fam)
         tot_fl = sum(r.flops for r in recs[:n])
         top = fam[0]
+        pmc = pmc_record(top["kernel"])
         roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": FP32_MATRIX_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": top["tflops"] / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": top["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
+                "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                "traffic_source": pmc.get("source") if pmc else None,
+                "mfma_busy_pmc": pmc.get("mfma_busy") if pmc else None,
                 "avg_launch_us": top["avg_us"], "launches_per_step": top["launches"],
                 "all_conv_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
                                      "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,

@@ -27,11 +27,6 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
     return 1.f;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 // Sum over the 64 lanes with DPP row shifts / row broadcasts (VALU only -- no LDS round trips like the
 // ds_bpermute behind __shfl_xor): six dependent adds.  The total is valid in LANE 63 only.
 template <int CTRL, int ROW = 0xf, int BANK = 0xf>
@@ -46,6 +41,10 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
     v += dpp_mov0<0x142, 0xa>(v);         // row_bcast:15 into rows 1 and 3
     v += dpp_mov0<0x143, 0xc>(v);         // row_bcast:31 into rows 2 and 3
     return v;
+}
+// full-wave sum, result in every lane (lane 63's total broadcast through an SGPR); call in convergent code only
+__device__ __forceinline__ float wave_sum(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
