@@ -199,8 +199,8 @@ def main():
         L.mgvae_prof_enable(1)
         step(*batch)
         torch.cuda.synchronize()
-        recs = (nat.ProfRec * 32)()
-        n = L.mgvae_prof_collect(recs, 32)
+        recs = (nat.ProfRec * 40)()
+        n = L.mgvae_prof_collect(recs, 40)
         L.mgvae_prof_enable(0)
         L.mgvae_prof_detail(b"")
         fam = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,

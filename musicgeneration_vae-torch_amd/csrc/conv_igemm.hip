@@ -448,6 +448,162 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const IgemmP p, int J) {
     }
 }
 
+// =======================================================================================
+// Skinny GEMMs: the Linear layers (H = W = 1, 1x1 kernel) at batch <= 128 -- z-discriminators, the
+// encoder / decoder fully connected layers, the flattened decoder stems.  The tiled kernel above is
+// latency-bound there (20 us for 33 MFLOP: one 64-wide pixel tile, K walked serially through LDS).
+// Here the batch IS the MFMA column block and nothing goes through LDS on the way in: with a K chunk
+// of 8 laid out as k = kb + 4*h + s (h = lane >> 5, s = MFMA step 0..3), both operands of
+// v_mfma_f32_32x32x2_f32 are one float4 global load per lane (row = lane & 31, 16 contiguous bytes).
+// A workgroup owns 32 output features; its four waves interleave the K chunks and combine through
+// LDS, then write rows of 32 contiguous features.  grid.y splits K further (atomics into a
+// zeroed output, activation by a follow-up pass) only when grid.x alone cannot fill the chip.
+struct SkinnyP {
+    const float* A;      // weight: [I][K] (A_KI = false) or [K][I] (A_KI = true), leading dimension a_ld
+    const float* B;      // activations [N rows][K], row stride b_ld (channel-sliced buffers)
+    const float* bias;   // [I] or null
+    float* out;          // [N rows][I], row stride o_ld
+    int I, N, K, a_ld, b_ld, o_ld, act, kchunk;
+    float slope;
+};
+
+template <int NT, bool A_KI>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyP p) {
+    // 4 waves share one block of 32 output features: wave w takes the K chunks (of 8) w, w+4, ...; the problem is
+    // latency-bound (few waves, every load a miss), so a wave first issues the loads of CH chunks, then multiplies.
+    // The four partial blocks meet in LDS (one slab per wave -- LDS float atomics serialise per lane), two column
+    // tiles at a time.
+    constexpr int CH = NT <= 2 ? 4 : 3;
+    constexpr int STRIDE = 4 * 8;
+    constexpr int TP = NT < 2 ? NT : 2;                 // column tiles per reduction pass
+    __shared__ float red[4][TP * 32][33];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * 32;
+    const int kbeg = blockIdx.y * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+    // rows past the edge are clamped, computed and never written: no predication on the loads
+    const int ia = min(i0 + l31, p.I - 1);
+    const float* ap = A_KI ? p.A + ia : p.A + (size_t)ia * p.a_ld;
+    const float* bp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bp[t] = p.B + (size_t)min(32 * t + l31, p.N - 1) * p.b_ld;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int kb0 = kbeg + wave * 8; kb0 < kend; kb0 += STRIDE * CH) {
+        float4 a[CH], b[CH][NT];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = min(kb0 + c * STRIDE, kend - 8) + 4 * h;      // clamped: a chunk past the end is loaded, not used
+            if constexpr (A_KI) {
+                a[c].x = ap[(size_t)k * p.a_ld]; a[c].y = ap[(size_t)(k + 1) * p.a_ld];
+                a[c].z = ap[(size_t)(k + 2) * p.a_ld]; a[c].w = ap[(size_t)(k + 3) * p.a_ld];
+            } else {
+                a[c] = *reinterpret_cast<const float4*>(ap + k);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[c][t] = *reinterpret_cast<const float4*>(bp[t] + k);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // all CH chunks' loads are in flight before the first MFMA waits
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            // a chunk past the end multiplies zeros (no branch: the compiler would sink the loads into it)
+            const float m = (kb0 + c * STRIDE < kend) ? 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x * m, b[c][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y * m, b[c][t].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z * m, b[c][t].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w * m, b[c][t].w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += TP) {
+        if (t0 > 0) __syncthreads();                   // the previous pass has been read
+#pragma unroll
+        for (int t = 0; t < TP; ++t)
+            if (t0 + t < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)           // D row (i) = (r&3) + 8*(r>>2) + 4*h ; D col (j) = lane & 31
+                    red[wave][32 * t + l31][(r & 3) + 8 * (r >> 2) + 4 * h] = acc[t0 + t][r];
+            }
+        __syncthreads();
+        for (int e = tid; e < TP * 32 * 32; e += 256) {
+            const int il = e & 31, jl = e >> 5;
+            const int i = i0 + il, j = 32 * t0 + jl;
+            if (i < p.I && j < p.N) {
+                float v = (red[0][jl][il] + red[1][jl][il]) + (red[2][jl][il] + red[3][jl][il]);
+                float* o = p.out + (size_t)j * p.o_ld + i;
+                if (gridDim.y > 1) {
+                    if (p.bias && blockIdx.y == 0) v += p.bias[i];
+                    atomicAdd(o, v);
+                } else {
+                    if (p.bias) v += p.bias[i];
+                    *o = apply_act(v, p.act, p.slope);
+                }
+            }
+        }
+    }
+}
+
+// dW[i][j] += sum_n dy[n][i] * x[n][j]: the reduction is only the batch, the output is the whole weight -- bound
+// by the read-modify-write of dW.  One wave owns a 32 x (32*TJ) block for the full batch (no split, so plain +=,
+// no atomics); both operands are lane-contiguous 128-byte rows; eight k-steps of loads are issued before their MFMAs.
+template <int TJ>
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ x,
+                                                           int x_ld, float* __restrict__ dw, int I, int J, int N) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i0 = (blockIdx.y * 4 + wave) * 32, j0 = blockIdx.x * 32 * TJ;
+    if (i0 >= I) return;
+    const float* ap = dy + min(i0 + l31, I - 1);
+    const float* bp[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) bp[t] = x + min(j0 + 32 * t + l31, J - 1);
+    f32x16 acc[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int k = 0; k < N; k += 16) {
+        float a[8], b[8][TJ];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k + 2 * u + h;
+            const int kc = min(kk, N - 1);             // clamped; a row past the batch is zeroed below
+            a[u] = ap[(size_t)kc * dy_ld];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) b[u][t] = bp[t][(size_t)kc * x_ld];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // eight k-steps of loads in flight before the first MFMA waits
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float av = (k + 2 * u + h) < N ? a[u] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][t], acc[t], 0, 0, 0);
+        }
+    }
+    // read-modify-write of the owned block: all 16 reads of a column tile in flight, then the adds and stores
+    // (rows / columns past the edge are clamped for the read and skipped for the write)
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+        const int j = j0 + 32 * t + l31;
+        const int jc = min(j, J - 1);
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = dw[(size_t)min(i0 + (r & 3) + 8 * (r >> 2) + 4 * h, I - 1) * J + jc];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i < I && j < J) dw[(size_t)i * J + j] = old[r] + acc[t][r];
+        }
+    }
+}
+
 // zero / activate a channel-sliced tensor [N, C, P] living in a buffer with ctot channels
 __global__ __launch_bounds__(256) void slice_zero_kernel(float* __restrict__ t, long row, long pitch, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -809,6 +965,50 @@ static std::vector<Choice> gemm_candidates(long I, long J, int Z, long Kmin) {
     return v;
 }
 
+// ---- skinny (Linear, batch <= 128) dispatch --------------------------------------------------------------
+static bool skinny_enabled() {
+    static const int v = getenv("MGVAE_SKINNY") ? atoi(getenv("MGVAE_SKINNY")) : 1;
+    return v != 0;
+}
+static bool is_linear(const MgvaeConvDesc* d) {
+    return d->H == 1 && d->W == 1 && d->OH == 1 && d->OW == 1 && d->KH == 1 && d->KW == 1 && d->N <= 128;
+}
+static void skinny_note(const MgvaeConvDesc* d, unsigned gx, unsigned gy) {
+    g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = 1; g_prof_note[3] = 1; g_prof_note[4] = d->Cy;
+    g_prof_note[5] = 1; g_prof_note[6] = 1; g_prof_note[7] = 1; g_prof_note[8] = 1; g_prof_note[9] = 1; g_prof_note[10] = 1;
+    g_prof_note[11] = gx; g_prof_note[12] = gy; g_prof_note[13] = 1;
+}
+// out[n][i] = act(bias[i] + sum_k A(i,k) * B[n][k]).  Returns false when the shape / alignment does not qualify.
+static bool skinny_gemm(const MgvaeConvDesc* d, int mode, const float* A, bool a_ki, int I, int K, const float* B, int b_ld,
+                        const float* bias, float* out, int o_ld, hipStream_t s, void* stream) {
+    if (!skinny_enabled() || (K & 7) || (b_ld & 3) || ((uintptr_t)B & 15) || (!a_ki && ((uintptr_t)A & 15))) return false;
+    SkinnyP p{A, B, bias, out, I, d->N, K, a_ki ? I : K, b_ld, o_ld, d->act, 0, d->slope};
+    const int gx = cdiv(I, 32);
+    int ks = 1;                                            // split K only while the chip is under-filled and K is deep
+    while (gx * ks < g_cus && K / (ks * 2) >= 512) ks *= 2;  // a wave then walks >= 128 of K: >= 4 rounds of loads
+    p.kchunk = cdiv(cdiv(K, ks), 32) * 32;
+    ks = cdiv(K, p.kchunk);
+    const dim3 grid(gx, ks);
+    const int nt = cdiv(d->N, 32);
+    if (ks > 1) zero_slice(out, d->N, I, 1, o_ld, s);
+    void* tok = nullptr;
+    skinny_note(d, grid.x, grid.y);
+    mgvae_prof_record_begin(mode, 5, 2.0 * I * (double)K * d->N, stream, &tok);
+#define MGVAE_SK(NT)                                                                                         \
+    if (a_ki) hipLaunchKernelGGL((skinny_gemm_kernel<NT, true>), grid, dim3(256), 0, s, p);                 \
+    else hipLaunchKernelGGL((skinny_gemm_kernel<NT, false>), grid, dim3(256), 0, s, p)
+    switch (nt) {
+        case 1: MGVAE_SK(1); break;
+        case 2: MGVAE_SK(2); break;
+        case 3: MGVAE_SK(3); break;
+        default: MGVAE_SK(4); break;
+    }
+#undef MGVAE_SK
+    mgvae_prof_record_end(tok, stream);
+    if (ks > 1 && d->act != MGVAE_ACT_NONE) act_slice(out, d->N, I, 1, o_ld, d->act, d->slope, s);
+    return true;
+}
+
 extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
                                 float* y, void* stream) {
     int rc = validate(d);
@@ -824,7 +1024,7 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
         g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
         g_prof_note[5] = d->OH; g_prof_note[6] = d->OW; g_prof_note[7] = d->KH; g_prof_note[8] = d->KW; g_prof_note[9] = d->SH;
         g_prof_note[10] = d->SW; g_prof_note[11] = grid.x; g_prof_note[12] = grid.y; g_prof_note[13] = 1;
-        mgvae_prof_record_begin(MODE_FWD, 3, 2.0 * I * J * K, stream, &tok);
+        mgvae_prof_record_begin(MODE_FWD, 6, 2.0 * I * J * K, stream, &tok);
 #define MGVAE_THIN_FWD(JM)                                                                                              \
     switch (d->act) {                                                                                                   \
         case MGVAE_ACT_RELU: hipLaunchKernelGGL((thin_fwd_kernel<JM, MGVAE_ACT_RELU>), grid, dim3(256), 0, s, p, (int)K); break;       \
@@ -835,6 +1035,11 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
         if (K <= 4) { MGVAE_THIN_FWD(4) } else { MGVAE_THIN_FWD(16) }
 #undef MGVAE_THIN_FWD
         mgvae_prof_record_end(tok, stream);
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
+    if (is_linear(d) && skinny_gemm(d, MODE_FWD, w, false, d->Cy, d->Cx, x + d->x_coff, d->x_ctot, bias, y + d->y_coff,
+                                    d->y_ctot, s, stream)) {
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
     }
@@ -861,6 +1066,11 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
     int rc = validate(d);
     if (rc) return rc;
     if (!x || !w || !y) return MGVAE_EINVAL;
+    if (is_linear(d) && skinny_gemm(d, MODE_BWD_DATA, w, true, d->Cx, d->Cy, y + d->y_coff, d->y_ctot, bias, x + d->x_coff,
+                                    d->x_ctot, as_stream(stream), stream)) {      // KH*KW == 1: w_t has w's layout
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
     IgemmP p = make_params(d);
     p.Y = y; p.Wt = w; p.bias = bias; p.out = x + (size_t)d->x_coff * d->H * d->W; p.X = nullptr;
     rc = get_ktab(d, MODE_BWD_DATA, p, wtrans);
@@ -1015,9 +1225,20 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
         if (gx > cap) gx = cap;
         const dim3 grid((unsigned)gx, ycount, 1);
         g_prof_note[10] = d->SW; g_prof_note[11] = grid.x; g_prof_note[12] = grid.y; g_prof_note[13] = grid.z;
-        mgvae_prof_record_begin(MODE_BWD_WEIGHT, 3, fl, stream, &tok);
+        mgvae_prof_record_begin(MODE_BWD_WEIGHT, 6, fl, stream, &tok);
         if (J <= 4) hipLaunchKernelGGL((thin_bwd_weight_kernel<32, 4>), grid, dim3(256), 0, as_stream(stream), q, J);
         else hipLaunchKernelGGL((thin_bwd_weight_kernel<8, 16>), grid, dim3(256), 0, as_stream(stream), q, J);
+        mgvae_prof_record_end(tok, stream);
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
+    if (is_linear(d) && skinny_enabled()) {
+        const dim3 grid(cdiv(d->Cx, 128), cdiv(d->Cy, 128));
+        void* tok = nullptr;
+        skinny_note(d, grid.x, grid.y);
+        mgvae_prof_record_begin(MODE_BWD_WEIGHT, 5, 2.0 * d->Cy * (double)d->Cx * d->N, stream, &tok);
+        hipLaunchKernelGGL(skinny_wgrad_kernel<4>, grid, dim3(256), 0, as_stream(stream), y + d->y_coff, d->y_ctot, x + d->x_coff,
+                           d->x_ctot, dw, d->Cy, d->Cx, d->N);
         mgvae_prof_record_end(tok, stream);
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
@@ -1095,14 +1316,14 @@ extern "C" int mgvae_prof_detail(const char* path) {
 
 extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    MgvaeProfRec recs[25];
+    MgvaeProfRec recs[35];
     for (int k = 0; k < 5; ++k)
-        for (int t = 0; t < 5; ++t) recs[k * 5 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
+        for (int t = 0; t < 7; ++t) recs[k * 7 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
     for (auto& pe : g_prof_entries) {
         float ms = 0.f;
         hipEventSynchronize(pe.e1);
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
-        MgvaeProfRec& r = recs[pe.kind * 5 + pe.tile];
+        MgvaeProfRec& r = recs[pe.kind * 7 + pe.tile];
         r.launches += 1; r.ms += ms; r.flops += pe.flops;
         if (g_prof_detail) {
             const IgemmP& q = pe.p;
@@ -1115,16 +1336,18 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     g_prof_entries.clear();
     if (g_prof_detail) fflush(g_prof_detail);
     int n = 0;
-    for (int i = 0; i < 25 && n < cap; ++i)
+    for (int i = 0; i < 35 && n < cap; ++i)
         if (recs[i].launches > 0) out[n++] = recs[i];
     return n;
 }
 
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
-    static char buf[5][5][48];
-    if (kind < 0 || kind > 4 || tile < 0 || tile > 4) return "?";
-    if (kind < 3) snprintf(buf[kind][tile], 48, "igemm_kernel<%d, %s>", kind, tiles[tile]);
+    static char buf[5][7][48];
+    if (kind < 0 || kind > 4 || tile < 0 || tile > 6) return "?";
+    if (tile == 5) snprintf(buf[kind][tile], 48, kind == 2 ? "skinny_wgrad_kernel" : "skinny_gemm_kernel (%s)", kind == 0 ? "fwd" : "bwd_data");
+    else if (tile == 6) snprintf(buf[kind][tile], 48, kind == 2 ? "thin_bwd_weight_kernel" : "thin_fwd_kernel");
+    else if (kind < 3) snprintf(buf[kind][tile], 48, "igemm_kernel<%d, %s>", kind, tiles[tile]);
     else snprintf(buf[kind][tile], 48, "dconv_kernel<%s> (%s)", tiles[tile], kind == 3 ? "fwd" : "bwd_data");
     return buf[kind][tile];
 }

@@ -144,6 +144,38 @@ def test_conv2d_fwd_bwd(g, conv_path):
         check("conv2d db %s" % (g,), bd.grad, br.grad)
 
 
+@pytest.mark.parametrize("N,K,I", [(64, 512, 512), (128, 1152, 512), (5, 192, 1), (33, 1152, 70), (64, 2304, 1152), (96, 6144, 40)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_skinny_gemm(N, K, I, act):
+    """nn.Linear at batch <= 128 takes the skinny-GEMM kernels (no LDS staging, batch = MFMA columns): forward,
+    data gradient, weight gradient (accumulating), with column-sliced input and output buffers."""
+    hf = HF()
+    x = torch.randn(N, K); w = torch.randn(I, K) * 0.05; b = torch.randn(I)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    if act:
+        yr = F.relu(yr)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xbuf = torch.zeros(N, K + 64, device=dev)
+    xbuf[:, 32:32 + K] = x.to(dev)
+    xd = xbuf[:, 32:32 + K].detach().requires_grad_(True)          # a column slice: row stride K + 64
+    wd = torch.nn.Parameter(w.to(dev)); bd = torch.nn.Parameter(b.to(dev))
+    obuf = torch.full((N, I + 8), 7.0, device=dev)
+    y = hf.linear(xd, wd, bd, act=act, out=obuf[:, 4:4 + I])
+    tag = "linear N%d K%d I%d act%d" % (N, K, I, act)
+    check(tag + " fwd", y, yr)
+    assert float(obuf[:, :4].min()) == 7.0 and float(obuf[:, 4 + I:].min()) == 7.0     # neighbours untouched
+    y.backward(dy.float().to(dev))
+    check(tag + " dx", xd.grad, xr.grad)
+    check(tag + " dw", wd.grad, wr.grad)
+    check(tag + " db", bd.grad, br.grad)
+    # a second backward accumulates into the same gradient
+    y2 = hf.linear(xd, wd, bd, act=act)
+    y2.backward(dy.float().to(dev))
+    check(tag + " dw x2", wd.grad, 2 * wr.grad)
+
+
 def test_conv2d_fused_activations_and_channel_slices(conv_path):
     x = torch.randn(3, 24, 10, 7)
     w = torch.randn(16, 8, 3, 3) * 0.3
