@@ -1045,16 +1045,16 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     }
     rc = get_ktab(d, MODE_FWD, p);
     if (rc) return rc;
-    if (autotune_on() && !is_capturing(s)) {
+    if (autotune_on()) {
         const KtabKey key = choice_key(d, MODE_FWD, 0);
         Choice c;
-        bool have;
-        have = choice_lookup(key, &c);
-        if (!have) {
+        bool have = choice_lookup(key, &c);
+        if (!have && !is_capturing(s)) {       // no trial launches under stream capture; a cached decision is still used
             c = tune(gemm_candidates(I, J, 1, K), [&](const Choice& q) { return exec_fwd(d, p, q.tile, q.split, s); }, s);
             choice_store(key, c);
+            have = true;
         }
-        return exec_fwd(d, p, c.tile, c.split, s);
+        if (have) return exec_fwd(d, p, c.tile, c.split, s);
     }
     int ksplit = 1;
     const int tile = pick_tile(I, J, 1, K, &ksplit);
@@ -1082,16 +1082,16 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
     const long J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
     // smallest per-phase K: Cy * (fewest taps a phase has, at least 1)
     const long tmin = (long)(d->KH / d->SH > 0 ? d->KH / d->SH : 1) * (d->KW / d->SW > 0 ? d->KW / d->SW : 1);
-    if (autotune_on() && !is_capturing(s)) {
+    if (autotune_on()) {
         const KtabKey key = choice_key(d, MODE_BWD_DATA, wtrans);
         Choice c;
-        bool have;
-        have = choice_lookup(key, &c);
-        if (!have) {
+        bool have = choice_lookup(key, &c);
+        if (!have && !is_capturing(s)) {
             c = tune(gemm_candidates(I, J, Z, (long)d->Cy * tmin), [&](const Choice& q) { return exec_bwd_data(d, p, q.tile, q.split, s); }, s);
             choice_store(key, c);
+            have = true;
         }
-        return exec_bwd_data(d, p, c.tile, c.split, s);
+        if (have) return exec_bwd_data(d, p, c.tile, c.split, s);
     }
     int ksplit = 1;
     const int tile = pick_tile(I, J, Z, (long)d->Cy * tmin, &ksplit);
@@ -1248,12 +1248,11 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
     hipStream_t s = as_stream(stream);
     const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
     const long max_splits = cdiv(M, BK * 8);
-    if (autotune_on() && !is_capturing(s)) {
+    if (autotune_on()) {
         const KtabKey key = choice_key(d, MODE_BWD_WEIGHT, 0);
         Choice c;
-        bool have;
-        have = choice_lookup(key, &c);
-        if (!have) {
+        bool have = choice_lookup(key, &c);
+        if (!have && !is_capturing(s)) {
             // trial launches accumulate, so they write a scratch gradient, never the caller's
             float* scratch = nullptr;
             if (hipMalloc(&scratch, (size_t)I * J * sizeof(float)) == hipSuccess) {

@@ -710,9 +710,11 @@ def dropout(x, p=0.3, training=True, mask=None):
     return _DropoutFn.apply(x, p, mask)
 
 
-def randn(shape, sigma=1.0, device="cuda"):
-    """Gaussian prior noise N(0, sigma^2) generated on the device (agent/barGen2.py:243,250)"""
-    out = torch.empty(shape, device=device, dtype=torch.float32)
+def randn(shape, sigma=1.0, device="cuda", out=None):
+    """Gaussian prior noise N(0, sigma^2) generated on the device (agent/barGen2.py:243,250); ``out``: fill this
+    dense fp32 tensor instead of allocating (static buffers of a captured graph)"""
+    if out is None:
+        out = torch.empty(shape, device=device, dtype=torch.float32)
     nat.check(nat.lib().mgvae_randn(_p(out), out.numel(), sigma, _rng_state["seed"], _next_offset(), _s()), "randn")
     return out
 

@@ -47,6 +47,61 @@ def sample(gen, music_length=10, songs=1, device="cuda"):
     return torch.cat(out, dim=1)
 
 
+class GraphSampler:
+    """The same loop with the two device programs -- "encode the previous phrase" (once per phrase) and "decode one
+    bar" (encoder of the previous bar, decoder, optional refiner, threshold) -- captured ONCE as HIP graphs over
+    static buffers and replayed: a sampling call at batch 32 is ~200 short launches, i.e. bound by the host's launch
+    rate, not by the GPU.  Prior noise is drawn outside the graph (its Philox offset advances per call).
+    Capture needs every conv geometry to have been seen (gather tables, autotuner), hence the eager warm-up."""
+
+    def __init__(self, gen, songs=1, device="cuda"):
+        self.gen, self.songs, self.device = gen, songs, device
+        self.pre_phrase = torch.zeros(songs, 1, 384, 60, device=device)
+        self.pre_bar = torch.zeros(songs, 1, 96, 60, device=device)
+        self.z = torch.zeros(songs, 1152, device=device)
+        self.pos = torch.zeros(songs, device=device, dtype=torch.long)
+        self.pf = torch.zeros(songs, 1152, device=device)
+        with torch.no_grad():
+            for _ in range(2):                       # eager warm-up on the capture inputs' shapes
+                self._phrase_program()
+                self._bar_program()
+            torch.cuda.synchronize()
+            self.g_phrase, self.g_bar = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_phrase):
+                self._phrase_program()
+            with torch.cuda.graph(self.g_bar, pool=self.g_phrase.pool()):
+                self._bar_program()
+        self.pre_bar.zero_()
+
+    def _phrase_program(self):
+        self.pf.copy_(self.gen.phrase_encoder(self.pre_phrase))
+
+    def _bar_program(self):
+        gen = self.gen
+        bar = gen.decoder(self.z, gen.encoder(self.pre_bar), self.pf, self.pos)
+        if getattr(gen, "use_refiner", False):
+            bar = gen.refiner(bar)
+        self.pre_bar.copy_(torch.gt(bar, 0.3).float())
+
+    @torch.no_grad()
+    def sample(self, music_length=10):
+        """[songs, music_length * 384, 60] binary rolls, same schedule as ``sample``"""
+        S = self.songs
+        self.pre_phrase.zero_()
+        self.pre_bar.zero_()
+        phrase_idx = [330] + list(range(music_length - 2, -1, -1))
+        out = torch.empty(S, music_length * 384, 60, device=self.device)
+        for idx in range(music_length):
+            self.pos.fill_(phrase_idx[idx])
+            self.g_phrase.replay()
+            for b in range(4):
+                HF.randn((S, 1152), 1.0, self.device, out=self.z)
+                self.g_bar.replay()
+                out[:, idx * 384 + b * 96: idx * 384 + (b + 1) * 96].copy_(self.pre_bar.view(S, 96, 60))
+            self.pre_phrase.copy_(out[:, idx * 384:(idx + 1) * 384].reshape(S, 1, 384, 60))
+        return out
+
+
 def main():
     config = Config()
     device = torch.device("cuda", 0)

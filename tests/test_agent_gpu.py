@@ -134,3 +134,29 @@ def test_maker_bar_sampling_batch_of_songs():
     gen = Model().to("cuda").eval()
     roll = maker_bar.sample(gen, music_length=2, songs=3, device="cuda")
     assert tuple(roll.shape) == (3, 768, 60) and set(roll.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_graph_sampler_replays_the_eager_loop():
+    """the HIP-graph sampler (two captured device programs over static buffers) reproduces the eager sampling loop
+    bit for bit when the prior noise stream is the same, with and without the D2-fixed refiner"""
+    import __graft_entry__ as g
+    g.build()
+    import maker_bar
+    from graph.model import Model
+    from hipops import functional as HF
+    for refine in (False, True):
+        torch.manual_seed(3)
+        gen = Model(use_refiner=refine).to("cuda").eval()
+        with torch.no_grad():                       # tame the D4 N(-1,1) init so the bars are not all-on / all-off
+            for p in gen.parameters():
+                p.mul_(0.05)
+        HF.manual_seed(11)
+        want = maker_bar.sample(gen, music_length=3, songs=2, device="cuda")
+        gs = maker_bar.GraphSampler(gen, songs=2, device="cuda")
+        HF.manual_seed(11)
+        got = gs.sample(3)
+        assert tuple(got.shape) == (2, 3 * 384, 60)
+        assert float((got != want).float().mean()) < 2e-3, float((got != want).float().mean())
+        HF.manual_seed(11)
+        again = gs.sample(3)                         # replays are repeatable
+        assert float((again != got).float().mean()) < 2e-3
