@@ -77,6 +77,22 @@ int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx, int KK, v
 int mgvae_conv2d_bwd_data_tw(const MgvaeConvDesc* d, const float* y, const float* w_t, const float* bias,
                              float* x, void* stream);
 /* dWt += corr(X, Y): weight gradient of either layer type (split-K, fp32 atomics)    */
+/* Activation-gradient mask for the *_masked entry points: out[n,c,p] *= act'(src[n, coff+c, p]) in the epilogue.
+ * `src` is shaped like the written tensor ([N, ctot, H, W] at channel offset coff).  Use: the layer that produced a
+ * conv's input fused an activation into its own forward (reference graph/encodingBlock.py:89-91: conv1 -> ReLU ->
+ * conv2); instead of a separate dy*act'(y) pass in that layer's backward, conv2's data gradient -- whose output
+ * has exactly that shape and whose saved input IS the activated tensor -- applies the factor while storing.
+ * act' is expressed through the activation's OUTPUT (relu: src>0; leaky: src>0 ? 1 : slope; sigmoid: src(1-src)). */
+typedef struct MgvaeActMask {
+    const float* src;
+    int32_t ctot, coff, act;
+    float slope;
+} MgvaeActMask;
+int mgvae_conv2d_fwd_masked(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                            const MgvaeActMask* mask, void* stream);   /* mask over Y: ConvTranspose2d d/dx */
+int mgvae_conv2d_bwd_data_masked(const MgvaeConvDesc* d, const float* y, const float* w, int w_transposed,
+                                 const float* bias, float* x, const MgvaeActMask* mask, void* stream);   /* mask over X */
+
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                             void* stream);
 /* Faster path of the two calls above: direct (halo-tile) convolution with pre-packed weights.

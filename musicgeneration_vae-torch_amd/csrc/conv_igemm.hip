@@ -43,6 +43,11 @@ struct IgemmP {
     int w_transposed;   // bwd_data: Wt is [Cy][KH*KW][Cx] (mgvae_weight_transpose) -> lane-contiguous A loads
     unsigned x_bytes, y_bytes, w_bytes;   // extents of X / Y / Wt for the buffer descriptors (< 4 GiB each)
     int xcd_remap;      // 1: workgroup ids are permuted so that each XCD (own L2) walks a contiguous run of tiles
+    // optional epilogue factor act'(m) read from a tensor shaped like the output (fwd / bwd_data): the activation
+    // gradient of the layer that PRODUCED this conv's input, folded into the conv's own data gradient
+    const float* mask;
+    int mask_ctot, mask_coff, mask_act;
+    float mask_slope;
 };
 
 // Operand loads go through buffer descriptors: a masked element gets the offset 0xFFFFFFFF, which the
@@ -376,14 +381,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         for (int tj = 0; tj < TJ; ++tj) {
             const int gj = j0 + wj * 32 * TJ + tj * 32 + l31;
             if (gj >= Jtot) continue;
-            int obase, cstride;
+            int obase, cstride, mbase = 0;
             if constexpr (MODE == MODE_FWD) {
                 const int n = gj / P, pp = gj - n * P;
                 obase = (n * p.y_ctot + p.y_coff) * P + pp; cstride = P;
+                mbase = (n * p.mask_ctot + p.mask_coff) * P + pp;
             } else {
                 const int n = gj / Pp, pp = gj - n * Pp;
                 const int a = pp / Wb, b = pp - a * Wb;
-                obase = (n * p.x_ctot + p.x_coff) * HW + (rh + p.SH * a) * p.W + rw + p.SW * b;
+                const int pix = (rh + p.SH * a) * p.W + rw + p.SW * b;
+                obase = (n * p.x_ctot + p.x_coff) * HW + pix;
+                mbase = (n * p.mask_ctot + p.mask_coff) * HW + pix;
                 cstride = HW;
             }
 #pragma unroll
@@ -393,12 +401,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
                     const int gi = i0 + wi * 32 * TI + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (gi < Itot) {
                         float v = acc[ti][tj][r];
+                        // act'(m) is a per-element factor, so it distributes over the K splits
+                        const float mk = p.mask ? act_grad_from_out(p.mask[mbase + gi * cstride], p.mask_act, p.mask_slope) : 1.f;
                         if (p.ksplit > 1) {       // split-K: caller zeroed the output, activation runs afterwards
                             if (p.bias && split == 0) v += p.bias[gi];
-                            atomicAdd(&p.out[obase + gi * cstride], v);
+                            atomicAdd(&p.out[obase + gi * cstride], v * mk);
                         } else {
                             if (p.bias) v += p.bias[gi];
-                            p.out[obase + gi * cstride] = apply_act(v, p.act, p.slope);
+                            p.out[obase + gi * cstride] = apply_act(v, p.act, p.slope) * mk;
                         }
                     }
                 }
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const IgemmP p, int J) {
         const float v = xb[ok ? cx * HW + r * p.W + c : 0];
         xv[j] = ok ? v : 0.f;
     }
-    float* ob = p.out + (size_t)n * p.y_ctot * P + i;
+    float* ob = p.out + ((size_t)n * p.y_ctot + p.y_coff) * P + i;
 #pragma unroll 8
     for (int cy = 0; cy < p.Cy; ++cy) {
         const float* wr = wsh + cy * J;
@@ -649,6 +659,7 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.KH = d->KH; p.KW = d->KW; p.SH = d->SH; p.SW = d->SW; p.PH = d->PH; p.PW = d->PW;
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
     p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0; p.w_transposed = 0;
+    p.mask = nullptr; p.mask_ctot = 0; p.mask_coff = 0; p.mask_act = MGVAE_ACT_NONE; p.mask_slope = 0.f;
     static const int xcd = getenv("MGVAE_XCD") ? atoi(getenv("MGVAE_XCD")) : 0;
     p.xcd_remap = xcd;
     p.x_bytes = (unsigned)((size_t)d->N * d->x_ctot * d->H * d->W * 4);
@@ -824,7 +835,7 @@ extern "C" int mgvae_prof_record_end(void* token, void* stream) {
 static int exec_fwd(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit, hipStream_t s) {
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
     const long P = (long)d->OH * d->OW;
-    float* y = p.out;
+    float* y = p.out + (size_t)d->y_coff * P;          // first channel of the written slice
     p.ksplit = ksplit;
     if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(y, d->N, d->Cy, P, d->y_ctot, s); }
     dim3 grid(cdiv(J, tile_jt(tile)), cdiv(I, tile_it(tile)), ksplit);
@@ -837,7 +848,7 @@ static int exec_bwd_data(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit,
     const int Z = d->SH * d->SW;
     const long I = d->Cx, J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
     const long HW = (long)d->H * d->W;
-    float* x = p.out;
+    float* x = p.out + (size_t)d->x_coff * HW;         // first channel of the written slice
     p.ksplit = ksplit;
     if (ksplit > 1) { p.act = MGVAE_ACT_NONE; zero_slice(x, d->N, d->Cx, HW, d->x_ctot, s); }
     dim3 grid(cdiv(J, tile_jt(tile)), cdiv(I, tile_it(tile)), Z * ksplit);
@@ -1009,16 +1020,27 @@ static bool skinny_gemm(const MgvaeConvDesc* d, int mode, const float* A, bool a
     return true;
 }
 
-extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
-                                float* y, void* stream) {
+static int check_mask(const MgvaeActMask* m, int C) {
+    if (!m) return MGVAE_OK;
+    if (!m->src || m->coff < 0 || m->coff + C > m->ctot || m->act < MGVAE_ACT_NONE || m->act > MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
+    return MGVAE_OK;
+}
+static void set_mask(IgemmP& p, const MgvaeActMask* m) {
+    if (!m) return;
+    p.mask = m->src; p.mask_ctot = m->ctot; p.mask_coff = m->coff; p.mask_act = m->act; p.mask_slope = m->slope;
+}
+
+static int fwd_impl(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias, float* y, void* stream,
+                    const MgvaeActMask* m) {
     int rc = validate(d);
     if (rc) return rc;
-    if (!x || !w || !y) return MGVAE_EINVAL;
+    if (!x || !w || !y || check_mask(m, d ? d->Cy : 0)) return MGVAE_EINVAL;
     IgemmP p = make_params(d);
-    p.X = x; p.Wt = w; p.bias = bias; p.out = y + (size_t)d->y_coff * d->OH * d->OW; p.Y = nullptr;
+    p.X = x; p.Wt = w; p.bias = bias; p.out = y; p.Y = nullptr;     // kernels add y_coff themselves
+    set_mask(p, m);
     hipStream_t s = as_stream(stream);
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW, K = (long)d->Cx * d->KH * d->KW;
-    if (K <= 16 && d->N <= 65535 && I * K <= THIN_W_MAX && I <= THIN_W_MAX / 4) {
+    if (!m && K <= 16 && d->N <= 65535 && I * K <= THIN_W_MAX && I <= THIN_W_MAX / 4) {
         const dim3 grid(cdiv((long)d->OH * d->OW, 256), d->N);
         void* tok = nullptr;
         g_prof_note[0] = d->N; g_prof_note[1] = d->Cx; g_prof_note[2] = d->H; g_prof_note[3] = d->W; g_prof_note[4] = d->Cy;
@@ -1038,7 +1060,7 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
     }
-    if (is_linear(d) && skinny_gemm(d, MODE_FWD, w, false, d->Cy, d->Cx, x + d->x_coff, d->x_ctot, bias, y + d->y_coff,
+    if (!m && is_linear(d) && skinny_gemm(d, MODE_FWD, w, false, d->Cy, d->Cx, x + d->x_coff, d->x_ctot, bias, y + d->y_coff,
                                     d->y_ctot, s, stream)) {
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
@@ -1061,18 +1083,28 @@ extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const fl
     return exec_fwd(d, p, tile, ksplit, s);
 }
 
+extern "C" int mgvae_conv2d_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
+                                float* y, void* stream) {
+    return fwd_impl(d, x, w, bias, y, stream, nullptr);
+}
+extern "C" int mgvae_conv2d_fwd_masked(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias,
+                                       float* y, const MgvaeActMask* mask, void* stream) {
+    return fwd_impl(d, x, w, bias, y, stream, mask);
+}
+
 static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias, float* x,
-                         void* stream, int wtrans) {
+                         void* stream, int wtrans, const MgvaeActMask* m = nullptr) {
     int rc = validate(d);
     if (rc) return rc;
-    if (!x || !w || !y) return MGVAE_EINVAL;
-    if (is_linear(d) && skinny_gemm(d, MODE_BWD_DATA, w, true, d->Cx, d->Cy, y + d->y_coff, d->y_ctot, bias, x + d->x_coff,
+    if (!x || !w || !y || check_mask(m, d ? d->Cx : 0)) return MGVAE_EINVAL;
+    if (!m && is_linear(d) && skinny_gemm(d, MODE_BWD_DATA, w, true, d->Cx, d->Cy, y + d->y_coff, d->y_ctot, bias, x + d->x_coff,
                                     d->x_ctot, as_stream(stream), stream)) {      // KH*KW == 1: w_t has w's layout
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
     }
     IgemmP p = make_params(d);
-    p.Y = y; p.Wt = w; p.bias = bias; p.out = x + (size_t)d->x_coff * d->H * d->W; p.X = nullptr;
+    p.Y = y; p.Wt = w; p.bias = bias; p.out = x; p.X = nullptr;     // kernels add x_coff themselves
+    set_mask(p, m);
     rc = get_ktab(d, MODE_BWD_DATA, p, wtrans);
     p.w_transposed = wtrans;
     if (rc) return rc;
@@ -1101,6 +1133,12 @@ static int bwd_data_impl(const MgvaeConvDesc* d, const float* y, const float* w,
 extern "C" int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias,
                                      float* x, void* stream) {
     return bwd_data_impl(d, y, w, bias, x, stream, 0);
+}
+
+// X = conv_transpose(Y, Wt) * act'(mask): w_transposed selects the weight layout of the two entry points above/below
+extern "C" int mgvae_conv2d_bwd_data_masked(const MgvaeConvDesc* d, const float* y, const float* w, int w_transposed,
+                                            const float* bias, float* x, const MgvaeActMask* mask, void* stream) {
+    return bwd_data_impl(d, y, w, bias, x, stream, w_transposed ? 1 : 0, mask);
 }
 
 // same with w_t = mgvae_weight_transpose(w): [Cy][KH*KW][Cx], so the weight operand loads are

@@ -27,8 +27,8 @@ class _Stem(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
-        o = getattr(self, self.first)(x, act=HF.ACT_RELU)
-        o = getattr(self, self.second)(o)
+        o = getattr(self, self.first)(x, act=HF.ACT_RELU, defer_act_grad=True)      # ReLU' applied by the consumer below
+        o = getattr(self, self.second)(o, in_act=(HF.ACT_RELU, 0.0))
         return self.cbam.fused_norm(o, self.bn, 1, act=HF.ACT_RELU, out=out)
 
 

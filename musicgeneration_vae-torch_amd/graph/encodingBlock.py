@@ -26,8 +26,9 @@ class _Stem(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
-        o = getattr(self, self.first)(x, act=HF.ACT_LEAKY, slope=0.01)
-        o = getattr(self, self.second)(o)
+        # the LeakyReLU gradient of the first conv is applied by the second conv's data gradient (its only consumer)
+        o = getattr(self, self.first)(x, act=HF.ACT_LEAKY, slope=0.01, defer_act_grad=True)
+        o = getattr(self, self.second)(o, in_act=(HF.ACT_LEAKY, 0.01))
         return self.cbam.fused_norm(o, self.bn, 1, act=HF.ACT_LEAKY, slope=0.01, out=out)
 
 
@@ -53,7 +54,8 @@ class ResidualModule(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
-        o = self.conv2(self.conv1(x, act=HF.ACT_RELU))
+        # conv1's ReLU gradient is applied by conv2's data gradient (conv2 is the only consumer of relu(conv1(x)))
+        o = self.conv2(self.conv1(x, act=HF.ACT_RELU, defer_act_grad=True), in_act=(HF.ACT_RELU, 0.0))
         return self.cbam.fused_norm(o, self.bn, 2, res=x, act=HF.ACT_RELU, out=out)
 
 

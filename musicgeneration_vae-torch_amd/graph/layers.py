@@ -31,8 +31,9 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         _default_init(self.weight, self.bias, in_channels * self.kernel_size[0] * self.kernel_size[1])
 
-    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
-        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, slope, out)
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None, in_act=None, defer_act_grad=False):
+        """in_act / defer_act_grad: see hipops.functional._ConvFn (activation gradient folded into the consumer)"""
+        return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, slope, out, in_act, defer_act_grad)
 
 
 class ConvTranspose2d(nn.Module):
@@ -45,8 +46,9 @@ class ConvTranspose2d(nn.Module):
         # torch derives fan_in of a transposed-conv weight from dim 1
         _default_init(self.weight, self.bias, out_channels * self.kernel_size[0] * self.kernel_size[1])
 
-    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
-        return HF.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope, out)
+    def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None, in_act=None, defer_act_grad=False):
+        return HF.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope, out,
+                                   in_act, defer_act_grad)
 
 
 class Linear(nn.Module):

@@ -20,6 +20,12 @@ class ConvDesc(ctypes.Structure):
         "x_ctot", "x_coff", "y_ctot", "y_coff", "act")] + [("slope", ctypes.c_float)]
 
 
+class ActMask(ctypes.Structure):
+    """MgvaeActMask (include/mgvae.h)"""
+    _fields_ = [("src", ctypes.c_void_p), ("ctot", ctypes.c_int32), ("coff", ctypes.c_int32), ("act", ctypes.c_int32),
+                ("slope", ctypes.c_float)]
+
+
 class ProfRec(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("tile", ctypes.c_int32), ("launches", ctypes.c_int32),
                 ("ms", ctypes.c_double), ("flops", ctypes.c_double)]
@@ -34,6 +40,8 @@ SIGNATURES = {
     "mgvae_conv2d_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, P]),
     "mgvae_conv2d_bwd_data_tw": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
+    "mgvae_conv2d_fwd_masked": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_bwd_data_masked": (c_int, [ctypes.POINTER(ConvDesc), P, P, c_int, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),

@@ -84,11 +84,24 @@ def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
 
 USE_TRANSPOSED_W = True   # data-gradient / transposed-conv kernels read a [Cy][KK][Cx] copy of the weight
 USE_DIRECT = False  # direct (halo-tile, packed-weight) conv kernels; False = implicit-GEMM fallback only
+import os as _os
+DEFER_ACT_GRAD = _os.environ.get("MGVAE_DEFER_ACT", "1") != "0"   # fold act' into the consumer's data gradient
 
 
-def _conv_fwd(d, x, w, b, y):
-    """Y = conv(X, Wt): direct kernel when the geometry is supported, else implicit GEMM"""
+def _mask(t, act, slope):
+    """MgvaeActMask over tensor ``t`` (the activated tensor whose act'(.) multiplies the conv's output)"""
+    t, ct = _sliceable(t)
+    return nat.ActMask(t.data_ptr(), ct, 0, act, slope), t
+
+
+def _conv_fwd(d, x, w, b, y, mask=None):
+    """Y = conv(X, Wt): direct kernel when the geometry is supported, else implicit GEMM; ``mask`` = (tensor, act,
+    slope): multiply Y by act'(tensor) in the epilogue"""
     L = nat.lib()
+    if mask is not None:
+        m, keep = _mask(*mask)
+        nat.check(L.mgvae_conv2d_fwd_masked(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), ctypes.byref(m), _s()), "conv2d_fwd_masked")
+        return
     n = L.mgvae_conv_pack_floats(ctypes.byref(d), 0) if USE_DIRECT else 0
     if n:
         wp = torch.empty((n,), device=w.device, dtype=torch.float32)
@@ -98,9 +111,19 @@ def _conv_fwd(d, x, w, b, y):
         nat.check(L.mgvae_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv2d_fwd")
 
 
-def _conv_bwd_data(d, y, w, b, x):
-    """X = conv_transpose(Y, Wt) (+bias): direct per-phase kernels when supported"""
+def _conv_bwd_data(d, y, w, b, x, mask=None):
+    """X = conv_transpose(Y, Wt) (+bias): direct per-phase kernels when supported; ``mask`` as in _conv_fwd (over X)"""
     L = nat.lib()
+    if mask is not None:
+        m, keep = _mask(*mask)
+        tw = d.KH * d.KW > 1 and USE_TRANSPOSED_W
+        if tw:
+            wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            nat.check(L.mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
+            w = wt
+        nat.check(L.mgvae_conv2d_bwd_data_masked(ctypes.byref(d), _p(y), _p(w), 1 if tw else 0, _p(b), _p(x), ctypes.byref(m), _s()),
+                  "conv2d_bwd_data_masked")
+        return
     n = L.mgvae_conv_pack_floats(ctypes.byref(d), 1) if USE_DIRECT else 0
     if n:
         wp = torch.empty((n,), device=w.device, dtype=torch.float32)
@@ -130,7 +153,7 @@ class _ConvFn(torch.autograd.Function):
     graph/decoder.py:79,122,172,175) and, with H=W=1, nn.Linear."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, slope, out):
+    def forward(ctx, x, w, b, stride, pad, act, slope, out, in_act=None, defer_act_grad=False):
         _need_cuda(x, "conv2d")
         x, xct = _sliceable(x)
         N, Cx, H, W = x.shape
@@ -143,7 +166,13 @@ class _ConvFn(torch.autograd.Function):
         d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
         _conv_fwd(d, x, w, b, y)
         ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        # in_act = (act, slope): x is the ACTIVATED output of the producing layer, which skipped its own dy*act'(y)
+        # pass (defer_act_grad there); this conv's data gradient applies act'(x) while storing.  The two flags must
+        # be used as a pair, and only when this conv is the sole consumer of x.
+        if not DEFER_ACT_GRAD:
+            in_act, defer_act_grad = None, False
+        ctx.in_act, ctx.defer = in_act, bool(defer_act_grad)
+        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer_act_grad) else None)
         ctx.b = b
         return y
 
@@ -152,7 +181,7 @@ class _ConvFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, Cx, H, W, Cy, OH, OW, k, s, p, xct, act, slope = ctx.geom
         L = nat.lib()
-        if act != ACT_NONE:
+        if act != ACT_NONE and not ctx.defer:
             dy = _act_bwd(y, dy, act, slope)
         dy, dct = _sliceable(dy)
         d = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, xct, dct, ACT_NONE, 0.0)
@@ -165,12 +194,12 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, Cx, H, W), device=dy.device, dtype=torch.float32)
             d2 = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, Cx, dct, ACT_NONE, 0.0)
-            _conv_bwd_data(d2, dy, w, None, dx)
-        return dx, None, None, None, None, None, None, None
+            _conv_bwd_data(d2, dy, w, None, dx, mask=(x,) + tuple(ctx.in_act) if ctx.in_act else None)
+        return dx, None, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=(1, 1), pad=(0, 0), act=ACT_NONE, slope=0.01, out=None):
-    return _ConvFn.apply(x, w, b, stride, pad, act, slope, out)
+def conv2d(x, w, b=None, stride=(1, 1), pad=(0, 0), act=ACT_NONE, slope=0.01, out=None, in_act=None, defer_act_grad=False):
+    return _ConvFn.apply(x, w, b, stride, pad, act, slope, out, in_act, defer_act_grad)
 
 
 def linear(x, w, b=None, act=ACT_NONE, slope=0.01, out=None):
@@ -187,7 +216,7 @@ class _ConvTFn(torch.autograd.Function):
     stride-phase data-gradient kernel, d/dx is the forward-conv kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, opad, act, slope, out):
+    def forward(ctx, x, w, b, stride, pad, opad, act, slope, out, in_act=None, defer_act_grad=False):
         _need_cuda(x, "conv_transpose2d")
         x, xct = _sliceable(x)
         N, Ci, h, wd = x.shape
@@ -207,7 +236,10 @@ class _ConvTFn(torch.autograd.Function):
         d = _desc(N, Co, OH, OW, Ci, h, wd, k, stride, pad, yct, xct, act, slope)
         _conv_bwd_data(d, x, w, b, y)
         ctx.geom = (N, Co, OH, OW, Ci, h, wd, k, stride, pad, xct, act, slope)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        if not DEFER_ACT_GRAD:
+            in_act, defer_act_grad = None, False
+        ctx.in_act, ctx.defer = in_act, bool(defer_act_grad)      # see _ConvFn.forward
+        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer_act_grad) else None)
         ctx.b = b
         return y
 
@@ -216,7 +248,7 @@ class _ConvTFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, Co, OH, OW, Ci, h, wd, k, s, p, xct, act, slope = ctx.geom
         L = nat.lib()
-        if act != ACT_NONE:
+        if act != ACT_NONE and not ctx.defer:
             dy = _act_bwd(y, dy, act, slope)
         dy, dct = _sliceable(dy)
         if Co != dy.shape[1]:      # flattened 1x1-input case (see forward): dy [N, co, KH, KW] -> [N, co*KH*KW, 1, 1]
@@ -233,12 +265,13 @@ class _ConvTFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, Ci, h, wd), device=dy.device, dtype=torch.float32)
             d2 = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, Ci, ACT_NONE, 0.0)
-            _conv_fwd(d2, dy, w, None, dx)
-        return dx, None, None, None, None, None, None, None, None
+            _conv_fwd(d2, dy, w, None, dx, mask=(x,) + tuple(ctx.in_act) if ctx.in_act else None)
+        return dx, None, None, None, None, None, None, None, None, None, None
 
 
-def conv_transpose2d(x, w, b=None, stride=(1, 1), pad=(0, 0), opad=(0, 0), act=ACT_NONE, slope=0.01, out=None):
-    return _ConvTFn.apply(x, w, b, stride, pad, opad, act, slope, out)
+def conv_transpose2d(x, w, b=None, stride=(1, 1), pad=(0, 0), opad=(0, 0), act=ACT_NONE, slope=0.01, out=None, in_act=None,
+                     defer_act_grad=False):
+    return _ConvTFn.apply(x, w, b, stride, pad, opad, act, slope, out, in_act, defer_act_grad)
 
 
 # ====================================================================== instance norm

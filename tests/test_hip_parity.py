@@ -731,3 +731,61 @@ def test_variational_encoder_flag():
         # eval returns the mean (no sampling); split-K atomics / autotuned configurations make the last
         # bits run-dependent and the N(-1,1)-initialised trunk amplifies them to ~1e-4 relative
         assert torch.allclose(enc(x), enc(x), rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("geom", [(3, 8, 10, 7, 16, 3, 1, 1), (2, 64, 12, 8, 128, 3, 2, 1), (4, 40, 1, 1, 24, 1, 1, 0),
+                                  (2, 1, 20, 12, 8, 3, 1, 1), (2, 256, 6, 4, 512, 3, 1, 1)])
+def test_c_abi_channel_offsets(geom):
+    """x_coff / y_coff of MgvaeConvDesc (the host layer always passes 0 and offsets the pointer instead): all three
+    conv entry points must address [N, ctot, H, W] buffers at a channel offset, tiled, split-K, thin and skinny."""
+    import ctypes
+    from hipops import _native as nat
+    L = nat.lib()
+    N, Cx, H, W_, Cy, k, st, pd = geom
+    OH, OW = (H + 2 * pd - k) // st + 1, (W_ + 2 * pd - k) // st + 1
+    xc, xo, yc, yo = Cx + 5, 3, Cy + 7, 4
+    xb = torch.randn(N, xc, H, W_); yb = torch.randn(N, yc, OH, OW); w = torch.randn(Cy, Cx, k, k) * 0.1
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, st, st, pd, pd, xc, xo, yc, yo, 0, 0.0)
+    xs, ys = xb[:, xo:xo + Cx].double(), yb[:, yo:yo + Cy].double()
+    # forward into the y slice
+    xd, yd, wd = xb.to(dev), yb.to(dev), w.to(dev)
+    assert L.mgvae_conv2d_fwd(ctypes.byref(d), vp(xd), vp(wd), None, vp(yd), s) == 0
+    want = yb.double().clone(); want[:, yo:yo + Cy] = F.conv2d(xs, w.double(), None, st, pd)
+    check("abi coff fwd %s" % (geom,), yd, want)
+    # data gradient into the x slice
+    xd2 = xb.to(dev); yd2 = yb.to(dev)
+    assert L.mgvae_conv2d_bwd_data(ctypes.byref(d), vp(yd2), vp(wd), None, vp(xd2), s) == 0
+    wantx = xb.double().clone()
+    wantx[:, xo:xo + Cx] = torch.nn.grad.conv2d_input(xs.shape, w.double(), ys, st, pd)
+    check("abi coff bwd_data %s" % (geom,), xd2, wantx)
+    # weight gradient (accumulates)
+    dw = torch.ones_like(wd)
+    assert L.mgvae_conv2d_bwd_weight(ctypes.byref(d), vp(xb.to(dev)), vp(yb.to(dev)), vp(dw), s) == 0
+    check("abi coff bwd_weight %s" % (geom,), dw, 1.0 + torch.nn.grad.conv2d_weight(xs, w.shape, ys, st, pd))
+
+
+@pytest.mark.parametrize("geom", [(3, 16, 10, 7, 24, (3, 3), (1, 1), (1, 1)), (2, 32, 24, 10, 32, (1, 4), (1, 2), (0, 1)),
+                                  (4, 512, 6, 4, 512, (3, 3), (1, 1), (1, 1)), (2, 20, 9, 9, 12, (3, 3), (2, 2), (1, 1))])
+@pytest.mark.parametrize("act", [1, 2])
+def test_deferred_activation_gradient(geom, act):
+    """conv1 -> act -> conv2 with the activation's gradient folded into conv2's data gradient (masked epilogue,
+    incl. split-K and strided phases) equals the unfused chain and the fp64 reference."""
+    N, C, H, W_, Co, k, s, p = geom
+    hf = HF()
+    x = torch.randn(N, C, H, W_); w1 = torch.randn(C, C, 3, 3) * 0.2; w2 = torch.randn(Co, C, *k) * 0.2
+    fn = (None, F.relu, lambda t: F.leaky_relu(t, 0.01))[act]
+    xr, w1r, w2r = (t.double().requires_grad_(True) for t in (x, w1, w2))
+    yr = F.conv2d(fn(F.conv2d(xr, w1r, None, 1, 1)), w2r, None, s, p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_(True); w1d = torch.nn.Parameter(w1.to(dev)); w2d = torch.nn.Parameter(w2.to(dev))
+    h = hf.conv2d(xd, w1d, None, (1, 1), (1, 1), act, 0.01, defer_act_grad=True)
+    y = hf.conv2d(h, w2d, None, s, p, in_act=(act, 0.01))
+    tag = "deferred act grad %s act%d" % (geom, act)
+    check(tag + " fwd", y, yr)
+    y.backward(dy.float().to(dev))
+    check_grad(tag + " dx", xd.grad, xr.grad)
+    check(tag + " dw2", w2d.grad, w2r.grad)
+    check_grad(tag + " dw1", w1d.grad, w1r.grad)
