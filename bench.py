@@ -36,6 +36,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MATRIX_PEAK_TFLOPS = 2500.0         # dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
 FLOP_PER_BAR_STEP = 29.5e9               # 3 x 9.83 GFLOP forward
 
 
@@ -119,6 +120,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="bars per GPU")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="matrix-operand precision of the conv kernels; f32 is BASELINE.json's metric config (configs[1]), "
+                         "bf16 (operands bf16, accumulate fp32, tensors and master weights fp32) is configs[2]/[3]'s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-detail", default="", help="write one CSV row per conv launch of the profiled step")
@@ -150,6 +154,8 @@ def main():
     from graph.model import Model
     from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
     from graph.loss.bar_loss import Loss, DLoss
+    HF.set_compute_dtype(args.dtype)
+    peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
 
     arch = ctypes.create_string_buffer(64)
     cus = ctypes.c_int(0)
@@ -210,14 +216,14 @@ def main():
         tot_fl = sum(r.flops for r in recs[:n])
         top = fam[0]
         pmc = pmc_record(top["kernel"])
-        roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": FP32_MATRIX_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": top["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
+        roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": peak,
+                "unit": "TFLOP/s", "frac": top["tflops"] / peak,
                 "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
                 "traffic_source": pmc.get("source") if pmc else None,
                 "mfma_busy_pmc": pmc.get("mfma_busy") if pmc else None,
                 "avg_launch_us": top["avg_us"], "launches_per_step": top["launches"],
                 "all_conv_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
-                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                      "share_of_step_time": tot_ms / (1e3 * dt / args.steps)},
                 "variants": fam}
     base = None
@@ -231,7 +237,7 @@ def main():
         out = {
             "metric": "bars/sec VAE training step (fwd+bwd+opt) at 1/2/4/8 MI355X", "value": value, "unit": "bars/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "barGen2 pre-training generator step: PhraseEncoder + 2x Encoder + Decoder fwd, 3 frozen "
                                    "z-discriminators, Loss, bwd, Adam; Refiner excluded (reference defect D2)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,

@@ -77,6 +77,14 @@ int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx, int KK, v
 int mgvae_conv2d_bwd_data_tw(const MgvaeConvDesc* d, const float* y, const float* w_t, const float* bias,
                              float* x, void* stream);
 /* dWt += corr(X, Y): weight gradient of either layer type (split-K, fp32 atomics)    */
+/* Matrix-operand precision of the tiled conv kernels (process-wide; default fp32).  BF16 = BASELINE.json configs
+ * 3-4 ("bf16 compute / fp32 master weights"): tensors stay fp32 in HBM, operands are rounded to bf16 (RNE) while
+ * being staged, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16.  Thin (K<=16) and skinny (Linear) paths
+ * stay fp32. */
+enum { MGVAE_COMPUTE_F32 = 0, MGVAE_COMPUTE_BF16 = 1 };
+int mgvae_set_compute_dtype(int dtype);
+int mgvae_get_compute_dtype(void);
+
 /* Activation-gradient mask for the *_masked entry points: out[n,c,p] *= act'(src[n, coff+c, p]) in the epilogue.
  * `src` is shaped like the written tensor ([N, ctot, H, W] at channel offset coff).  Use: the layer that produced a
  * conv's input fused an activation into its own forward (reference graph/encodingBlock.py:89-91: conv1 -> ReLU ->

@@ -167,6 +167,7 @@ class AgentBase(object):
         torch.cuda.manual_seed_all(self.manual_seed)
         random.seed(self.manual_seed)
         HF.manual_seed(self.manual_seed, self.rank)
+        HF.set_compute_dtype(getattr(self.config, "compute_dtype", "f32"))
         if self.rank == 0:
             print("seed: ", self.manual_seed)
 

@@ -26,3 +26,5 @@ class Config(object):
     seed = None               # None -> random.randint(1, 10000) like the reference
     grad_bucket_mb = 64       # RCCL all-reduce bucket size
     log_file = 'train_epoch.log'
+    compute_dtype = 'f32'     # 'bf16': bf16 matrix operands / fp32 accumulate in the conv kernels (tensors, master weights
+                              # and Adam stay fp32) -- BASELINE.json configs 3-4

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -48,6 +49,7 @@ struct IgemmP {
     const float* mask;
     int mask_ctot, mask_coff, mask_act;
     float mask_slope;
+    int bf16;           // 1: igemm_bf16_kernel (bf16 operands, fp32 accumulate)
 };
 
 // Operand loads go through buffer descriptors: a masked element gets the offset 0xFFFFFFFF, which the
@@ -417,6 +419,330 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     }
 }
 
+// =======================================================================================
+// bf16-compute variant (BASELINE.json configs 3-4: "bf16 compute / fp32 master weights"): tensors stay fp32 in HBM,
+// the loaders round to bf16 (RNE, v_cvt_pk_bf16_f32) while staging into LDS and the product runs on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 1/16 of the matrix-pipe time of the fp32 kernel, half the LDS
+// traffic.  Every LDS image is [row][k] (k fastest, 40 bf16 = 80 B per row: 16-byte aligned rows whose ds_read_b128
+// fragment reads are bank-conflict-free): an MFMA operand is 8 consecutive k of one row = ONE 128-bit LDS read.
+//   * column-mapped loaders (a thread holds NB consecutive K rows of one column -- gathers, transposed weights):
+//     pack the NB values and store them as 128-bit rows;
+//   * k-mapped loaders (weights [cy][k], dY [cy][pix], the weight-gradient gather): a thread owns a PAIR of
+//     consecutive k = one packed dword.
+// Geometry tables, split-K, bias / activation / mask epilogue are those of the fp32 kernel.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16_t;
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    bf16x2_t v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int MODE, int TI, int TJ>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
+    constexpr int IT = 64 * TI, JT = 64 * TJ;
+    constexpr int BKc = 32, LDB = BKc + 8;
+    constexpr bool A_K = (MODE != MODE_BWD_DATA);      // A loaded with lanes along k
+    constexpr bool B_K = (MODE == MODE_BWD_WEIGHT);    // B loaded with lanes along k
+    constexpr int A_ELEMS = IT * LDB, B_ELEMS = JT * LDB;
+    constexpr int NA = IT * BKc / 256, NB = JT * BKc / 256;   // values per thread and K tile
+    constexpr int NA2 = NA / 2, NB2 = NB / 2;                  // k pairs per thread (k-mapped loaders)
+
+    __shared__ __attribute__((aligned(16))) u16_t lds[2 * (A_ELEMS + B_ELEMS)];
+    u16_t* As0 = lds;
+    u16_t* Bs0 = lds + 2 * A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.y * IT, j0 = blockIdx.x * JT;
+    const int bz = blockIdx.z;
+    const int HW = p.H * p.W, P = p.OH * p.OW;
+
+    int Itot, Jtot, kbeg, kend, T;
+    int rh = 0, rw = 0, Wb = 1, Pp = 1;
+    int Ktot = 0, split = 0;
+    if constexpr (MODE == MODE_FWD) {
+        Itot = p.Cy; Jtot = p.N * P; T = p.KH * p.KW; Ktot = p.Cx * T;
+        split = bz;
+        const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BKc - 1) / BKc * BKc;
+        kbeg = split * kc; kend = min(Ktot, kbeg + kc);
+    } else if constexpr (MODE == MODE_BWD_DATA) {
+        const int ph = bz / p.ksplit;
+        split = bz - ph * p.ksplit;
+        rh = ph / p.SW; rw = ph - rh * p.SW;
+        const int kh0 = (rh + p.PH) % p.SH, kw0 = (rw + p.PW) % p.SW;
+        const int nkh = kh0 < p.KH ? (p.KH - kh0 + p.SH - 1) / p.SH : 0;
+        const int nkw = kw0 < p.KW ? (p.KW - kw0 + p.SW - 1) / p.SW : 0;
+        const int Ha = rh < p.H ? (p.H - rh + p.SH - 1) / p.SH : 0;
+        Wb = rw < p.W ? (p.W - rw + p.SW - 1) / p.SW : 0;
+        Pp = Ha * Wb;
+        Itot = p.Cx; Jtot = p.N * Pp; T = nkh * nkw; Ktot = p.Cy * T;
+        const int kc = ((Ktot + p.ksplit - 1) / p.ksplit + BKc - 1) / BKc * BKc;
+        kbeg = split * kc; kend = min(Ktot, kbeg + kc);
+        if (split > 0 && kbeg >= Ktot) return;
+        if (Jtot == 0 || j0 >= Jtot) return;
+        if (T == 0) { T = 1; kbeg = 0; kend = 0; }
+    } else {
+        Itot = p.Cy; Jtot = p.Cx * p.KH * p.KW; T = 1;
+        kbeg = bz * p.kchunk;
+        kend = min(p.N * P, kbeg + p.kchunk);
+    }
+    const int2* __restrict__ ktab = p.ktab;
+    const int* __restrict__ wtab = p.wtab;
+    if constexpr (MODE == MODE_BWD_DATA) {
+        ktab += (size_t)(bz / p.ksplit) * p.ktab_stride;
+        wtab += (size_t)(bz / p.ksplit) * p.ktab_stride;
+    }
+
+    // column mapping: a wave-instruction covers 64 columns of one (wave-uniform) K row
+    constexpr int JC = JT / 64, IC = IT / 64;
+    const int jc = wave % JC, jkr0 = (wave / JC) * NB;
+    const int ic = wave % IC, ikr0 = (wave / IC) * NA;
+    // k mapping: 16 lanes x 2 consecutive k per row, 16 rows per pass
+    const int kl2 = (tid & 15) * 2, rr = tid >> 4;
+
+    bool bj_valid = false; int b_pix = 0, b_r0 = 0, b_c0 = 0, b_RH = 1, b_RW = 1;
+    bool ai_valid = false; int a_i = 0;
+    int w_n = 0, w_p = 0;                          // (sample, pixel) of this thread's FIRST k of the pair
+    int bj_off[NB2 > 0 ? NB2 : 1], bj_dh[NB2 > 0 ? NB2 : 1], bj_dw[NB2 > 0 ? NB2 : 1];
+    (void)bj_off; (void)bj_dh; (void)bj_dw;
+
+    if constexpr (MODE == MODE_FWD) {
+        const int j = j0 + jc * 64 + lane;
+        bj_valid = j < Jtot;
+        const int jj = bj_valid ? j : 0;
+        const int n = jj / P, pp = jj - n * P;
+        const int oh = pp / p.OW, ow = pp - oh * p.OW;
+        b_r0 = oh * p.SH - p.PH; b_c0 = ow * p.SW - p.PW;
+        b_pix = (n * p.x_ctot + p.x_coff) * HW + b_r0 * p.W + b_c0;
+        b_RH = p.H; b_RW = p.W;
+    } else if constexpr (MODE == MODE_BWD_DATA) {
+        const int j = j0 + jc * 64 + lane;
+        bj_valid = j < Jtot;
+        const int jj = bj_valid ? j : 0;
+        const int n = jj / Pp, pp = jj - n * Pp;
+        const int a = pp / Wb, b = pp - a * Wb;
+        b_r0 = a; b_c0 = b;
+        b_pix = (n * p.y_ctot + p.y_coff) * P + a * p.OW + b;
+        b_RH = p.OH; b_RW = p.OW;
+        a_i = i0 + ic * 64 + lane;
+        ai_valid = a_i < Itot;
+    } else {
+        const int kp = kbeg + kl2;
+        w_n = kp / P; w_p = kp - w_n * P;
+#pragma unroll
+        for (int r = 0; r < NB2; ++r) {
+            const int gj = j0 + rr + 16 * r;
+            if (gj < Jtot) {
+                const int KK = p.KH * p.KW;
+                const int cx = gj / KK, t = gj - cx * KK;
+                const int kh = t / p.KW, kw = t - kh * p.KW;
+                bj_dh[r] = kh - p.PH; bj_dw[r] = kw - p.PW;
+                bj_off[r] = cx * HW + (kh - p.PH) * p.W + (kw - p.PW);
+            } else {
+                bj_dh[r] = -(1 << 28); bj_dw[r] = 0; bj_off[r] = 0;
+            }
+        }
+    }
+
+    float ra[NA], rb[NB];
+    const rsrc_t rX = make_rsrc(p.X, p.x_bytes), rY = make_rsrc(p.Y, p.y_bytes), rW = make_rsrc(p.Wt, p.w_bytes);
+    (void)rX; (void)rY; (void)rW;
+
+    auto load_tile = [&](int k0) {
+        // (sample, pixel) of the two k of this thread's pair (weight gradient only)
+        int n1 = w_n, p1 = w_p + 1;
+        if constexpr (MODE == MODE_BWD_WEIGHT) { if (p1 >= P) { p1 -= P; ++n1; } }
+        // ------------------------------ A operand ------------------------------
+        if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+            for (int r = 0; r < NA2; ++r) {
+                const int gi = i0 + rr + 16 * r;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int gk = k0 + kl2 + e;
+                    ra[2 * r + e] = buf_load(rW, gi * Ktot + gk, (gk < kend) & (gi < Itot));
+                }
+            }
+        } else if constexpr (MODE == MODE_BWD_DATA) {
+            const int KK = p.KH * p.KW;
+            const int ai_off = p.w_transposed ? a_i : a_i * KK;
+            const int* __restrict__ wt = wtab + (k0 + ikr0);
+            int wo[NA];
+#pragma unroll
+            for (int r = 0; r < NA; ++r) wo[r] = wt[r];
+#pragma unroll
+            for (int r = 0; r < NA; ++r) ra[r] = buf_load(rW, wo[r] + ai_off, ai_valid & ((k0 + ikr0 + r) < kend));
+        } else {
+            const int base0 = (w_n * p.y_ctot + p.y_coff) * P + w_p;
+            const int base1 = (n1 * p.y_ctot + p.y_coff) * P + p1;
+            const bool k0ok = (k0 + kl2) < kend, k1ok = (k0 + kl2 + 1) < kend;
+#pragma unroll
+            for (int r = 0; r < NA2; ++r) {
+                const int gi = i0 + rr + 16 * r;
+                ra[2 * r] = buf_load(rY, base0 + gi * P, k0ok & (gi < Itot));
+                ra[2 * r + 1] = buf_load(rY, base1 + gi * P, k1ok & (gi < Itot));
+            }
+        }
+        // ------------------------------ B operand ------------------------------
+        if constexpr (MODE != MODE_BWD_WEIGHT) {
+            const rsrc_t src = (MODE == MODE_FWD) ? rX : rY;
+            const int2* __restrict__ kt = ktab + (k0 + jkr0);
+            int2 e[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) e[r] = kt[r];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const int dh = (int)(short)(e[r].y & 0xffff), dw = e[r].y >> 16;
+                const bool ok = bj_valid & ((k0 + jkr0 + r) < kend) & ((unsigned)(b_r0 + dh) < (unsigned)b_RH) &
+                                ((unsigned)(b_c0 + dw) < (unsigned)b_RW);
+                rb[r] = buf_load(src, b_pix + e[r].x, ok);
+            }
+        } else {
+            const bool k0ok = (k0 + kl2) < kend, k1ok = (k0 + kl2 + 1) < kend;
+            const int oh0 = w_p / p.OW, ow0 = w_p - oh0 * p.OW;
+            const int oh1 = p1 / p.OW, ow1 = p1 - oh1 * p.OW;
+            const int r00 = oh0 * p.SH, c00 = ow0 * p.SW, r01 = oh1 * p.SH, c01 = ow1 * p.SW;
+            const int base0 = (w_n * p.x_ctot + p.x_coff) * HW + r00 * p.W + c00;
+            const int base1 = (n1 * p.x_ctot + p.x_coff) * HW + r01 * p.W + c01;
+#pragma unroll
+            for (int r = 0; r < NB2; ++r) {
+                const bool ok0 = k0ok & ((unsigned)(r00 + bj_dh[r]) < (unsigned)p.H) & ((unsigned)(c00 + bj_dw[r]) < (unsigned)p.W);
+                const bool ok1 = k1ok & ((unsigned)(r01 + bj_dh[r]) < (unsigned)p.H) & ((unsigned)(c01 + bj_dw[r]) < (unsigned)p.W);
+                rb[2 * r] = buf_load(rX, base0 + bj_off[r], ok0);
+                rb[2 * r + 1] = buf_load(rX, base1 + bj_off[r], ok1);
+            }
+            w_p += BKc;
+            while (w_p >= P) { w_p -= P; ++w_n; }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        u16_t* As = As0 + buf * A_ELEMS;
+        u16_t* Bs = Bs0 + buf * B_ELEMS;
+        if constexpr (A_K) {
+#pragma unroll
+            for (int r = 0; r < NA2; ++r)
+                *reinterpret_cast<unsigned*>(As + (rr + 16 * r) * LDB + kl2) = pack_bf16(ra[2 * r], ra[2 * r + 1]);
+        } else {
+            u16_t* row = As + (ic * 64 + lane) * LDB + ikr0;
+#pragma unroll
+            for (int q = 0; q < NA / 8; ++q)
+                *reinterpret_cast<uint4*>(row + 8 * q) =
+                    make_uint4(pack_bf16(ra[8 * q], ra[8 * q + 1]), pack_bf16(ra[8 * q + 2], ra[8 * q + 3]),
+                               pack_bf16(ra[8 * q + 4], ra[8 * q + 5]), pack_bf16(ra[8 * q + 6], ra[8 * q + 7]));
+        }
+        if constexpr (B_K) {
+#pragma unroll
+            for (int r = 0; r < NB2; ++r)
+                *reinterpret_cast<unsigned*>(Bs + (rr + 16 * r) * LDB + kl2) = pack_bf16(rb[2 * r], rb[2 * r + 1]);
+        } else {
+            u16_t* row = Bs + (jc * 64 + lane) * LDB + jkr0;
+#pragma unroll
+            for (int q = 0; q < NB / 8; ++q)
+                *reinterpret_cast<uint4*>(row + 8 * q) =
+                    make_uint4(pack_bf16(rb[8 * q], rb[8 * q + 1]), pack_bf16(rb[8 * q + 2], rb[8 * q + 3]),
+                               pack_bf16(rb[8 * q + 4], rb[8 * q + 5]), pack_bf16(rb[8 * q + 6], rb[8 * q + 7]));
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    const int nt = kend > kbeg ? (kend - kbeg + BKc - 1) / BKc : 0;
+    if (nt > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
+            const u16_t* As = As0 + buf * A_ELEMS;
+            const u16_t* Bs = Bs0 + buf * B_ELEMS;
+#pragma unroll
+            for (int ks = 0; ks < BKc / 16; ++ks) {
+                bf16x8_t a[TI], b[TJ];
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+                    a[ti] = *reinterpret_cast<const bf16x8_t*>(As + (wi * 32 * TI + ti * 32 + l31) * LDB + ks * 16 + h * 8);
+#pragma unroll
+                for (int tj = 0; tj < TJ; ++tj)
+                    b[tj] = *reinterpret_cast<const bf16x8_t*>(Bs + (wj * 32 * TJ + tj * 32 + l31) * LDB + ks * 16 + h * 8);
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TJ; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+            }
+            if (t + 1 < nt) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue (as in the fp32 kernel) -----------------------------------
+    if constexpr (MODE == MODE_BWD_WEIGHT) {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+            const int gj = j0 + wj * 32 * TJ + tj * 32 + l31;
+            if (gj >= Jtot) continue;
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = i0 + wi * 32 * TI + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (gi < Itot) atomicAdd(&p.out[(size_t)gi * Jtot + gj], acc[ti][tj][r]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tj = 0; tj < TJ; ++tj) {
+            const int gj = j0 + wj * 32 * TJ + tj * 32 + l31;
+            if (gj >= Jtot) continue;
+            int obase, cstride, mbase = 0;
+            if constexpr (MODE == MODE_FWD) {
+                const int n = gj / P, pp = gj - n * P;
+                obase = (n * p.y_ctot + p.y_coff) * P + pp; cstride = P;
+                mbase = (n * p.mask_ctot + p.mask_coff) * P + pp;
+            } else {
+                const int n = gj / Pp, pp = gj - n * Pp;
+                const int a = pp / Wb, b = pp - a * Wb;
+                const int pix = (rh + p.SH * a) * p.W + rw + p.SW * b;
+                obase = (n * p.x_ctot + p.x_coff) * HW + pix;
+                mbase = (n * p.mask_ctot + p.mask_coff) * HW + pix;
+                cstride = HW;
+            }
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gi = i0 + wi * 32 * TI + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (gi < Itot) {
+                        float v = acc[ti][tj][r];
+                        const float mk = p.mask ? act_grad_from_out(p.mask[mbase + gi * cstride], p.mask_act, p.mask_slope) : 1.f;
+                        if (p.ksplit > 1) {
+                            if (p.bias && split == 0) v += p.bias[gi];
+                            atomicAdd(&p.out[obase + gi * cstride], v * mk);
+                        } else {
+                            if (p.bias) v += p.bias[gi];
+                            p.out[obase + gi * cstride] = apply_act(v, p.act, p.slope) * mk;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Forward of a "thin" convolution (Cx*KH*KW <= 16: the C=1 stems of graph/encodingBlock.py:12-15 and the first
 // layers of graph/bar_discriminator.py): K <= 16 would idle the MFMA and the layer is bound by writing Y.  One
 // thread per output pixel gathers its <= 16 taps once and produces every output channel from them; the weights
@@ -653,6 +979,15 @@ static int validate(const MgvaeConvDesc* d) {
     return MGVAE_OK;
 }
 
+// matrix-operand precision of the tiled conv kernels (process-wide; the thin / skinny paths always run fp32)
+static std::atomic<int> g_compute_bf16{0};
+extern "C" int mgvae_set_compute_dtype(int dtype) {
+    if (dtype != MGVAE_COMPUTE_F32 && dtype != MGVAE_COMPUTE_BF16) return MGVAE_EINVAL;
+    g_compute_bf16.store(dtype == MGVAE_COMPUTE_BF16 ? 1 : 0);
+    return MGVAE_OK;
+}
+extern "C" int mgvae_get_compute_dtype(void) { return g_compute_bf16.load() ? MGVAE_COMPUTE_BF16 : MGVAE_COMPUTE_F32; }
+
 static IgemmP make_params(const MgvaeConvDesc* d) {
     IgemmP p{};
     p.N = d->N; p.Cx = d->Cx; p.H = d->H; p.W = d->W; p.Cy = d->Cy; p.OH = d->OH; p.OW = d->OW;
@@ -660,6 +995,7 @@ static IgemmP make_params(const MgvaeConvDesc* d) {
     p.x_ctot = d->x_ctot; p.x_coff = d->x_coff; p.y_ctot = d->y_ctot; p.y_coff = d->y_coff;
     p.act = d->act; p.slope = d->slope; p.kchunk = 0; p.ksplit = 1; p.ktab = nullptr; p.wtab = nullptr; p.ktab_stride = 0; p.w_transposed = 0;
     p.mask = nullptr; p.mask_ctot = 0; p.mask_coff = 0; p.mask_act = MGVAE_ACT_NONE; p.mask_slope = 0.f;
+    p.bf16 = g_compute_bf16.load(std::memory_order_relaxed);
     static const int xcd = getenv("MGVAE_XCD") ? atoi(getenv("MGVAE_XCD")) : 0;
     p.xcd_remap = xcd;
     p.x_bytes = (unsigned)((size_t)d->N * d->x_ctot * d->H * d->W * 4);
@@ -779,6 +1115,16 @@ static void act_slice(float* t, int N, int C, long P, int ctot, int act, float s
 
 template <int MODE>
 static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
+    if (p.bf16) {
+        switch (tile) {
+            case 0: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 2>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 1>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 1>), grid, dim3(256), 0, s, p); break;
+        }
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
     switch (tile) {
         case 0: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, p); break;
         case 1: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 2>), grid, dim3(256), 0, s, p); break;
@@ -933,7 +1279,7 @@ static bool is_capturing(hipStream_t s) {
     return st != hipStreamCaptureStatusNone;
 }
 static KtabKey choice_key(const MgvaeConvDesc* d, int mode, int wtrans) {
-    return KtabKey{{100 + mode + 16 * wtrans, d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->N}};
+    return KtabKey{{100 + mode + 16 * wtrans + 1000 * g_compute_bf16.load(std::memory_order_relaxed), d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->N}};
 }
 
 template <class Exec>
