@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="matrix-operand precision of the conv kernels; f32 is BASELINE.json's metric config (configs[1]), "
                          "bf16 (operands bf16, accumulate fp32, tensors and master weights fp32) is configs[2]/[3]'s")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step (zero_grad, fwd, losses, bwd, Adam) as one captured HIP graph; single GPU "
+                         "only.  Pays at small per-GPU batches (configs 3-4), where the host's launch rate bounds the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-detail", default="", help="write one CSV row per conv launch of the profiled step")
@@ -169,6 +172,12 @@ def main():
     HF.manual_seed(1234, rank)
     step = PretrainStep(gen, zb, zp, Loss().to(dev), DLoss(), lr=0.002)
     batch = synth_batch(args.batch, 1234 + rank, dev)
+    eager_step = step
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU: the bucketed all-reduce overlaps backward from autograd hooks")
+        from hipops.train import GraphedPretrainStep
+        step = GraphedPretrainStep(eager_step, *batch)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -203,7 +212,7 @@ def main():
         if args.prof_detail:
             L.mgvae_prof_detail(args.prof_detail.encode())
         L.mgvae_prof_enable(1)
-        step(*batch)
+        eager_step(*batch)           # per-launch events need real launches (not a graph replay)
         torch.cuda.synchronize()
         recs = (nat.ProfRec * 40)()
         n = L.mgvae_prof_collect(recs, 40)
@@ -241,6 +250,7 @@ def main():
             "config": {"workload": "barGen2 pre-training generator step: PhraseEncoder + 2x Encoder + Decoder fwd, 3 frozen "
                                    "z-discriminators, Loss, bwd, Adam; Refiner excluded (reference defect D2)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(args.graph),
                        "weights": "weights_init (D4) random", "device": arch.value.decode(), "cus": cus.value},
             "step_tflops": value * FLOP_PER_BAR_STEP / 1e12, "loss": final_loss,
             "roofline": roof, "cpu_baseline": base,

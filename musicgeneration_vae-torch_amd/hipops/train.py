@@ -67,4 +67,102 @@ class PretrainStep:
         return loss, gen
 
 
+class GraphedPretrainStep:
+    """``PretrainStep`` with zero_grad + forward + losses + backward + Adam captured ONCE as a HIP graph and replayed.
+
+    At 16-32 bars per GPU (BASELINE.json configs 3-4) the ~900 launches of a step cost the host more time than the
+    GPU needs to execute them; a replay is one launch.  What varies between iterations lives outside the capture:
+      * the batch: copied into static input buffers;
+      * dropout: the decoder's two masks are static tensors refreshed from the Philox stream before each replay
+        (a kernel's seed / offset arguments would be frozen by the capture);
+      * Adam's step-dependent scalars (lr / bias corrections): a pinned host vector that the captured H2D copy re-reads
+        at every replay (hipops.flat.FlatParams.step).
+    Single-process only: with torch.distributed up, use PretrainStep (its bucketed all-reduce overlaps backward from
+    autograd hooks, which a replay does not run)."""
+
+    def __init__(self, step, note, pre_note, phrase, position, is_pretraining=True, warmup=3):
+        import torch.cuda
+        from . import functional as HF
+        if hdist.is_dist():
+            raise RuntimeError("GraphedPretrainStep is single-process; use PretrainStep under torch.distributed")
+        self.step_obj, self.HF = step, HF
+        self.is_pretraining = is_pretraining
+        self.inputs = [t.clone() for t in (note, pre_note, phrase, position)]
+        dec = step.gen.decoder
+        self.dec = dec
+        B = note.shape[0]
+        self.masks = [torch.ones(B, 1152, device=note.device), torch.ones(B, 1152, device=note.device)]
+        self._ones = torch.ones(B, 1152, device=note.device)
+        self.use_masks = dec.training and dec.dropout_p > 0.0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up on a side stream, as torch's capture recipe asks
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self._refresh_masks()
+        self._set_hyper()                              # capture records, it does not execute: no step is consumed
+        with torch.cuda.graph(self.graph):
+            self.loss, self.gen_out = self._body()
+        torch.cuda.synchronize()
+
+    def _refresh_masks(self):
+        if self.use_masks:
+            for m in self.masks:
+                m.copy_(self.HF.dropout(self._ones, self.dec.dropout_p, True))
+            self.dec._drop_masks = self.masks
+        else:
+            self.dec._drop_masks = None
+
+    def _set_hyper(self):
+        import math
+        opt = self.step_obj.opt
+        b1, b2 = opt.betas
+        h = opt._hyper_host
+        h[0] = opt.param_groups[0]["lr"] / (1.0 - b1 ** opt.step_count)
+        h[1] = math.sqrt(1.0 - b2 ** opt.step_count)
+        h[2], h[3] = b1, b2
+
+    def _body(self):
+        """the captured program (also what the eager warm-up runs)"""
+        import ctypes
+        from graph.loss.bar_loss import DLoss
+        from . import _native as nat
+        st, opt = self.step_obj, self.step_obj.opt
+        note, pre_note, phrase, position = self.inputs
+        opt.zero_grad()
+        gen, z, pre_z, pf = st.gen(note, pre_note, phrase, position)
+        loss = DLoss.constant(st.zp(pf).view(-1), 1.0)
+        zz = _stacked(z, pre_z)
+        if zz is not None:
+            loss = loss + 2.0 * DLoss.constant(st.zb(zz).view(-1), 1.0)
+        else:
+            loss = loss + DLoss.constant(st.zb(z).view(-1), 1.0) + DLoss.constant(st.zb(pre_z).view(-1), 1.0)
+        loss = loss + st.loss_gen(gen, note, self.is_pretraining)
+        loss.backward()
+        opt._hyper.copy_(opt._hyper_host, non_blocking=True)       # re-read from the pinned vector at every replay
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        nat.check(nat.lib().mgvae_adam_step(vp(opt.flat), vp(opt.grad), vp(opt.exp_avg), vp(opt.exp_avg_sq), opt.numel,
+                                            vp(opt._hyper), opt.eps, 1.0, s), "adam_step")
+        return loss.detach(), gen.detach()
+
+    def _eager(self):
+        self._refresh_masks()
+        self.step_obj.opt.step_count += 1
+        self._set_hyper()
+        return self._body()
+
+    def __call__(self, note, pre_note, phrase, position):
+        for dst, src in zip(self.inputs, (note, pre_note, phrase, position)):
+            dst.copy_(src, non_blocking=True)
+        self._refresh_masks()
+        self.step_obj.opt.step_count += 1
+        self._set_hyper()
+        self.graph.replay()
+        return self.loss, self.gen_out
+
+
 from .dist import GradReducer  # noqa: E402

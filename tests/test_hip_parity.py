@@ -878,3 +878,54 @@ def test_train_step_bf16_close_to_fp32():
     rel = float((grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm())
     cos = float((grads["bf16"] * grads["f32"]).sum() / (grads["bf16"].norm() * grads["f32"].norm()))
     assert rel < 0.3 and cos > 0.97, (rel, cos)
+
+
+def test_graphed_train_step_matches_eager():
+    """the whole step replayed as one HIP graph == the eager step (same launches, same order): parameters after the
+    same number of Adam steps agree to split-K summation noise; Adam's bias correction and lr follow the host-side
+    step counter through the pinned hyper-parameter vector; dropout masks are refreshed between replays."""
+    import __graft_entry__ as ge
+    ge.build()
+    from graph.model import Model
+    from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
+    from graph.loss.bar_loss import Loss, DLoss
+    from hipops.train import PretrainStep, GraphedPretrainStep
+    hf = HF()
+    B = 2
+    g = torch.Generator().manual_seed(9)
+    batch = [(torch.rand(B, 1, 96, 60, generator=g) < 0.05).float().to(dev), (torch.rand(B, 1, 96, 60, generator=g) < 0.05).float().to(dev),
+             (torch.rand(B, 1, 384, 60, generator=g) < 0.05).float().to(dev), torch.randint(0, 332, (B,), generator=g).to(dev)]
+
+    def build():
+        torch.manual_seed(0)
+        gen, zb, zp = Model().to(dev), BarZDiscriminator().to(dev), PhraseZDiscriminator().to(dev)
+        with torch.no_grad():
+            for m in (gen, zb, zp):
+                for prm in m.parameters():
+                    prm.mul_(0.02)
+        gen.eval()                      # dropout off: both runs compute the same function
+        for d in (zb, zp):
+            for prm in d.parameters():
+                prm.requires_grad = False
+        return PretrainStep(gen, zb, zp, Loss().to(dev), DLoss().to(dev), lr=1e-3)
+
+    eager = build()
+    for _ in range(5):
+        le, _ = eager(*batch)
+    graphed_base = build()
+    gs = GraphedPretrainStep(graphed_base, *batch, warmup=3)
+    for _ in range(2):
+        lg, _ = gs(*batch)
+    assert graphed_base.opt.step_count == eager.opt.step_count == 5
+    a, b = eager.opt.flat.double().cpu(), graphed_base.opt.flat.double().cpu()
+    # Adam normalises every gradient to ~+-lr per step, so parameters whose gradient is pure summation noise (atomics
+    # order) may move by up to 2*lr*steps apart: compare in L2 over the whole vector, and through the loss
+    assert float((a - b).norm() / a.norm()) < 2e-2, float((a - b).norm() / a.norm())
+    assert float((a - b).abs().max()) <= 2 * 1e-3 * 5 + 1e-6
+    assert abs(float(lg) - float(le)) <= 1e-4 * abs(float(le)), (float(lg), float(le))
+    # training mode: the two dropout masks change between replays
+    graphed_base.gen.train()
+    gs2 = GraphedPretrainStep(graphed_base, *batch, warmup=1)
+    gs2(*batch); m0 = gs2.masks[0].clone()
+    gs2(*batch)
+    assert not torch.equal(m0, gs2.masks[0]) and set(gs2.masks[0].unique().tolist()) <= {0.0, 1.0 / 0.7} | {float(torch.tensor(1.0 / 0.7, dtype=torch.float32))}
