@@ -14,6 +14,10 @@ from graph.refiner import Refiner
 from graph.weights_initializer import weights_init
 
 
+import os
+OVERLAP_TRUNKS = os.environ.get("MGVAE_OVERLAP", "1") != "0"
+
+
 class Model(nn.Module):
     def __init__(self, use_refiner=False):
         super().__init__()
@@ -35,15 +39,37 @@ class Model(nn.Module):
         b = note.shape[0]
         return zz[:b], zz[b:]
 
+    def encode_phrase(self, phrase):
+        """the phrase encoder on a SIDE stream, concurrent with the bar encoder that the caller runs next on the current
+        stream (the two trunks are independent until the decoder; their small-map layers leave most CUs idle, so the
+        chains interleave).  Autograd replays each node on its forward stream, so the two backward trunks overlap too.
+        Call ``join_phrase`` before the result is consumed."""
+        if not OVERLAP_TRUNKS or not phrase.is_cuda:
+            return self.phrase_encoder(phrase)
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            pf = self.phrase_encoder(phrase)
+        pf.record_stream(cur)
+        return pf
+
+    def join_phrase(self):
+        if OVERLAP_TRUNKS and getattr(self, "_side", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def forward(self, note, pre_note, phrase, position, is_train=True):
-        phrase_feature = self.phrase_encoder(phrase)
+        phrase_feature = self.encode_phrase(phrase)
         if is_train:
             z, pre_z = self.encode_pair(note, pre_note)
+            self.join_phrase()
             gen = self.decoder(z, pre_z, phrase_feature, position)
             if self.use_refiner:
                 gen = self.refiner(gen)
             return gen, z, pre_z, phrase_feature
         # sampling: ``note`` is a latent [B,1152]
         pre_z = self.encoder(pre_note)
+        self.join_phrase()
         gen = self.decoder(note, pre_z, phrase_feature, position)
         return self.refiner(gen) if self.use_refiner else gen
