@@ -61,8 +61,10 @@ class DeConvModule(nn.Module):
         co = self.out_channel
         n, _, h, w = x.shape
         cat = torch.empty((n, 2 * co, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+        with HF.forked_branch(x, cat):            # the two transposed-conv branches are independent until the cat
+            b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.bn1(self.deConv1(x), act=HF.ACT_RELU, out=cat[:, :co])
-        b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
+        HF.join_side_streams()
         return self.cbam.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
 
 
@@ -87,8 +89,10 @@ class DeConvPitchPadding(nn.Module):
         co = self.out_channel
         n, _, h, w = x.shape
         cat = torch.empty((n, 2 * co, 2 * h, 2 * w + 1), device=x.device, dtype=torch.float32)
+        with HF.forked_branch(x, cat):
+            b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.cbam1.fused_norm(self.deConv1(x), self.bn2, 1, act=HF.ACT_RELU, out=cat[:, :co])
-        b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
+        HF.join_side_streams()
         return self.cbam2.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
 
 
@@ -137,8 +141,10 @@ class Decoder(nn.Module):
         xb = HF.copy_into(pf, xbuf[:, 1152:])
         x = HF.join(xbuf, xa, xb).view(n, 2304, 1, 1)
         cat = new(n, 2048, 6, 3)
+        with HF.forked_branch(x, cat):            # the two stems are independent until fit1
+            time = self.time(x, out=cat[:, 1024:])
         pitch = self.pitch(x, out=cat[:, :1024])
-        time = self.time(x, out=cat[:, 1024:])
+        HF.join_side_streams()
         o = self.cbam.fused_norm(self.fit1(HF.join(cat, pitch, time)), self.bn, 1, act=HF.ACT_RELU)
         for blk in self.layers:
             o = blk(o)

@@ -52,6 +52,9 @@ class GradReducer:
         """enqueue all-reduces for [start, end); returns immediately"""
         if not is_dist() or end <= start:
             return
+        if self.g.is_cuda:      # weight gradients may still be in flight on the side streams (functional._forked)
+            from . import functional as HF
+            HF.join_side_streams()
         for s, e in split_buckets(start, end, self.bucket_elems):
             self.pending.append(dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
         self.done_ranges.append((start, end))

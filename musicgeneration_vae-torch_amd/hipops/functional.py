@@ -148,6 +148,81 @@ def _conv_bwd_data(d, y, w, b, x, mask=None):
         nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d), _p(y), _p(w), _p(b), _p(x), _s()), "conv2d_bwd_data")
 
 
+# ---- side streams: independent work of one backward node (the weight gradient vs the data gradient of a conv) and
+# independent branches of the model run concurrently; under-filled launches (small maps, tiny GEMMs) then overlap.
+FORK_WGRAD = _os.environ.get("MGVAE_FORK_WGRAD", "1") != "0"
+_side_streams = {}      # (device index, id of the stream forked from) -> side stream
+_used_sides = {}        # streams with work of the running backward pass, to be joined by _join_sides
+_join_queued = [False]
+
+
+def side_stream_of(cur):
+    key = (cur.device.index, cur.cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=cur.device)
+        _side_streams[key] = st
+    return st
+
+
+def _join_sides():
+    """make the caller's stream wait for every side stream used since the last join (end of a backward pass)"""
+    cur = torch.cuda.current_stream()
+    for st in _used_sides.values():
+        cur.wait_stream(st)
+    _used_sides.clear()
+    _join_queued[0] = False
+
+
+def join_side_streams():
+    _join_sides()
+
+
+class _forked:
+    """``with _forked(tensors...)``: run the body on the side stream paired with the current stream, after everything
+    already enqueued on the current stream; the listed tensors are marked as in use there (caching allocator)."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        cur = torch.cuda.current_stream()
+        side = side_stream_of(cur)
+        side.wait_stream(cur)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        _used_sides[id(side)] = side
+        if not _join_queued[0] and torch._C._current_graph_task_id() != -1:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_sides)
+            _join_queued[0] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return side
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+
+FORK_BRANCHES = _os.environ.get("MGVAE_FORK_BRANCHES", "1") != "0"
+
+
+class forked_branch:
+    """``with forked_branch(x, buf):`` in a module's forward: run one of two independent branches on the side stream
+    (inputs / output buffers listed so the allocator knows); call ``join_side_streams()`` before the results meet.
+    A no-op context when disabled or on CPU tensors."""
+
+    def __init__(self, *tensors):
+        self.on = FORK_BRANCHES and all(t is None or t.is_cuda for t in tensors)
+        self.f = _forked(*tensors) if self.on else None
+
+    def __enter__(self):
+        return self.f.__enter__() if self.on else None
+
+    def __exit__(self, *a):
+        return self.f.__exit__(*a) if self.on else False
+
+
 def _act_bwd(y, dy, act, slope):
     """dx = dy * act'(y) -> dense tensor"""
     y, yct = _sliceable(y)
@@ -196,11 +271,19 @@ class _ConvFn(torch.autograd.Function):
             dy = _act_bwd(y, dy, act, slope)
         dy, dct = _sliceable(dy)
         d = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, xct, dct, ACT_NONE, 0.0)
-        if w.requires_grad:
-            nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_bwd_weight")
         b = ctx.b
-        if b is not None and b.requires_grad:
-            nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Cy, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
+
+        def weight_grads():
+            if w.requires_grad:
+                nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_bwd_weight")
+            if b is not None and b.requires_grad:
+                nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Cy, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
+
+        if FORK_WGRAD and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
+            with _forked(x, dy):          # the weight gradient runs beside the data gradient below
+                weight_grads()
+        else:
+            weight_grads()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, Cx, H, W), device=dy.device, dtype=torch.float32)
@@ -266,12 +349,20 @@ class _ConvTFn(torch.autograd.Function):
             if dct != dy.shape[1]:
                 dy = dy.contiguous()
             dy, dct = dy.view(N, Co, 1, 1), Co
-        if w.requires_grad:
-            d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
-            nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_bwd_weight")
         b = ctx.b
-        if b is not None and b.requires_grad:
-            nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Co, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
+
+        def weight_grads():
+            if w.requires_grad:
+                d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
+                nat.check(L.mgvae_conv2d_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_bwd_weight")
+            if b is not None and b.requires_grad:
+                nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Co, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
+
+        if FORK_WGRAD and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
+            with _forked(x, dy):
+                weight_grads()
+        else:
+            weight_grads()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, Ci, h, wd), device=dy.device, dtype=torch.float32)
