@@ -64,7 +64,7 @@ class DeConvModule(nn.Module):
         with HF.forked_branch(x, cat):            # the two transposed-conv branches are independent until the cat
             b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.bn1(self.deConv1(x), act=HF.ACT_RELU, out=cat[:, :co])
-        HF.join_side_streams()
+        HF.join_side_streams(slot=0)
         return self.cbam.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
 
 
@@ -92,7 +92,7 @@ class DeConvPitchPadding(nn.Module):
         with HF.forked_branch(x, cat):
             b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.cbam1.fused_norm(self.deConv1(x), self.bn2, 1, act=HF.ACT_RELU, out=cat[:, :co])
-        HF.join_side_streams()
+        HF.join_side_streams(slot=0)
         return self.cbam2.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
 
 
@@ -144,7 +144,7 @@ class Decoder(nn.Module):
         with HF.forked_branch(x, cat):            # the two stems are independent until fit1
             time = self.time(x, out=cat[:, 1024:])
         pitch = self.pitch(x, out=cat[:, :1024])
-        HF.join_side_streams()
+        HF.join_side_streams(slot=0)
         o = self.cbam.fused_norm(self.fit1(HF.join(cat, pitch, time)), self.bn, 1, act=HF.ACT_RELU)
         for blk in self.layers:
             o = blk(o)

@@ -156,8 +156,8 @@ _used_sides = {}        # streams with work of the running backward pass, to be 
 _join_queued = [False]
 
 
-def side_stream_of(cur):
-    key = (cur.device.index, cur.cuda_stream)
+def side_stream_of(cur, slot=0):
+    key = (cur.device.index, cur.cuda_stream, slot)
     st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=cur.device)
@@ -165,34 +165,38 @@ def side_stream_of(cur):
     return st
 
 
-def _join_sides():
-    """make the caller's stream wait for every side stream used since the last join (end of a backward pass)"""
+def _join_sides(slot=None):
+    """make the caller's stream wait for every side stream used since the last join (end of a backward pass);
+    ``slot``: only the side streams of that slot"""
     cur = torch.cuda.current_stream()
-    for st in _used_sides.values():
-        cur.wait_stream(st)
-    _used_sides.clear()
-    _join_queued[0] = False
+    for key in list(_used_sides):
+        st, sl = _used_sides[key]
+        if slot is None or sl == slot:
+            cur.wait_stream(st)
+            del _used_sides[key]
+    if slot is None:
+        _join_queued[0] = False
 
 
-def join_side_streams():
-    _join_sides()
+def join_side_streams(slot=None):
+    _join_sides(slot)
 
 
 class _forked:
     """``with _forked(tensors...)``: run the body on the side stream paired with the current stream, after everything
     already enqueued on the current stream; the listed tensors are marked as in use there (caching allocator)."""
 
-    def __init__(self, *tensors):
-        self.tensors = tensors
+    def __init__(self, *tensors, slot=0):
+        self.tensors, self.slot = tensors, slot
 
     def __enter__(self):
         cur = torch.cuda.current_stream()
-        side = side_stream_of(cur)
+        side = side_stream_of(cur, self.slot)
         side.wait_stream(cur)
         for t in self.tensors:
             if t is not None:
                 t.record_stream(side)
-        _used_sides[id(side)] = side
+        _used_sides[id(side)] = (side, self.slot)
         if not _join_queued[0] and torch._C._current_graph_task_id() != -1:
             torch.autograd.Variable._execution_engine.queue_callback(_join_sides)
             _join_queued[0] = True
@@ -204,7 +208,7 @@ class _forked:
         return self.ctx.__exit__(*a)
 
 
-FORK_BRANCHES = _os.environ.get("MGVAE_FORK_BRANCHES", "1") != "0"
+FORK_BRANCHES = _os.environ.get("MGVAE_FORK_BRANCHES", "0") != "0"   # measured: -0.5 % (decoder branches, z-losses) -> off
 
 
 class forked_branch:
@@ -212,9 +216,9 @@ class forked_branch:
     (inputs / output buffers listed so the allocator knows); call ``join_side_streams()`` before the results meet.
     A no-op context when disabled or on CPU tensors."""
 
-    def __init__(self, *tensors):
+    def __init__(self, *tensors, slot=0):
         self.on = FORK_BRANCHES and all(t is None or t.is_cuda for t in tensors)
-        self.f = _forked(*tensors) if self.on else None
+        self.f = _forked(*tensors, slot=slot) if self.on else None
 
     def __enter__(self):
         return self.f.__enter__() if self.on else None

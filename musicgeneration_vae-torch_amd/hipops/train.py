@@ -48,18 +48,39 @@ class PretrainStep:
         for t in tensors:
             t.register_hook(fire)
 
-    def __call__(self, note, pre_note, phrase, position, is_pretraining=True):
+    def forward_loss(self, note, pre_note, phrase, position, is_pretraining=True):
+        """generator forward + the four loss terms.  The three frozen z-discriminator passes depend only on the
+        encoders' outputs, like the decoder: they run on a side stream beside it (and so do their backward passes)."""
         from graph.loss.bar_loss import DLoss
-        self.opt.zero_grad()
-        gen, z, pre_z, pf = self.gen(note, pre_note, phrase, position)
-        self._arm_overlap((z, pre_z, pf))
-        loss = DLoss.constant(self.zp(pf).view(-1), 1.0)
-        zz = _stacked(z, pre_z)
-        if zz is not None:      # one discriminator pass over both latents: mean over 2B, twice = the two means over B
-            loss = loss + 2.0 * DLoss.constant(self.zb(zz).view(-1), 1.0)
+        from . import functional as HF
+        gen_m = self.gen
+
+        def z_losses(z, pre_z, pf):
+            loss = DLoss.constant(self.zp(pf).view(-1), 1.0)
+            zz = _stacked(z, pre_z)
+            if zz is not None:      # one discriminator pass over both latents: mean over 2B, twice = the two means over B
+                return loss + 2.0 * DLoss.constant(self.zb(zz).view(-1), 1.0)
+            return loss + DLoss.constant(self.zb(z).view(-1), 1.0) + DLoss.constant(self.zb(pre_z).view(-1), 1.0)
+
+        if hasattr(gen_m, "encode_pair") and not getattr(gen_m, "use_refiner", False) and hasattr(gen_m, "join_phrase"):
+            pf = gen_m.encode_phrase(phrase)
+            z, pre_z = gen_m.encode_pair(note, pre_note)
+            gen_m.join_phrase()
+            with HF.forked_branch(z, pre_z, pf, slot=1):      # slot 1: the decoder forks its own branches on slot 0
+                loss_z = z_losses(z, pre_z, pf)
+            gen = gen_m.decoder(z, pre_z, pf, position)
+            loss_g = self.loss_gen(gen, note, is_pretraining)
+            HF.join_side_streams(slot=1)
+            loss = loss_z + loss_g
         else:
-            loss = loss + DLoss.constant(self.zb(z).view(-1), 1.0) + DLoss.constant(self.zb(pre_z).view(-1), 1.0)
-        loss = loss + self.loss_gen(gen, note, is_pretraining)
+            gen, z, pre_z, pf = gen_m(note, pre_note, phrase, position)
+            loss = z_losses(z, pre_z, pf) + self.loss_gen(gen, note, is_pretraining)
+        return loss, gen, (z, pre_z, pf)
+
+    def __call__(self, note, pre_note, phrase, position, is_pretraining=True):
+        self.opt.zero_grad()
+        loss, gen, latents = self.forward_loss(note, pre_note, phrase, position, is_pretraining)
+        self._arm_overlap(latents)
         loss.backward()
         self.reducer.reduce_rest()
         self.reducer.wait()
@@ -133,14 +154,7 @@ class GraphedPretrainStep:
         st, opt = self.step_obj, self.step_obj.opt
         note, pre_note, phrase, position = self.inputs
         opt.zero_grad()
-        gen, z, pre_z, pf = st.gen(note, pre_note, phrase, position)
-        loss = DLoss.constant(st.zp(pf).view(-1), 1.0)
-        zz = _stacked(z, pre_z)
-        if zz is not None:
-            loss = loss + 2.0 * DLoss.constant(st.zb(zz).view(-1), 1.0)
-        else:
-            loss = loss + DLoss.constant(st.zb(z).view(-1), 1.0) + DLoss.constant(st.zb(pre_z).view(-1), 1.0)
-        loss = loss + st.loss_gen(gen, note, self.is_pretraining)
+        loss, gen, _ = st.forward_loss(note, pre_note, phrase, position, self.is_pretraining)
         loss.backward()
         opt._hyper.copy_(opt._hyper_host, non_blocking=True)       # re-read from the pinned vector at every replay
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
