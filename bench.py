@@ -211,9 +211,15 @@ def main():
         L = nat.lib()
         if args.prof_detail:
             L.mgvae_prof_detail(args.prof_detail.encode())
+        # ... on ONE stream: the timed steps overlap independent kernels on side streams (phrase / bar trunks, weight
+        # vs data gradients), which would charge every kernel for its neighbours' share of the chip
+        import graph.model as gm
+        saved = (HF.FORK_WGRAD, HF.FORK_BRANCHES, gm.OVERLAP_TRUNKS)
+        HF.FORK_WGRAD = HF.FORK_BRANCHES = gm.OVERLAP_TRUNKS = False
         L.mgvae_prof_enable(1)
         eager_step(*batch)           # per-launch events need real launches (not a graph replay)
         torch.cuda.synchronize()
+        HF.FORK_WGRAD, HF.FORK_BRANCHES, gm.OVERLAP_TRUNKS = saved
         recs = (nat.ProfRec * 40)()
         n = L.mgvae_prof_collect(recs, 40)
         L.mgvae_prof_enable(0)
@@ -231,6 +237,8 @@ def main():
                 "traffic_source": pmc.get("source") if pmc else None,
                 "mfma_busy_pmc": pmc.get("mfma_busy") if pmc else None,
                 "avg_launch_us": top["avg_us"], "launches_per_step": top["launches"],
+                "measured_in": "one extra untimed step with the side streams off (kernels alone on the chip); "
+                               "profiles/ holds rocprofv3 of the same command under MGVAE_SERIAL=1",
                 "all_conv_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
                                      "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                      "share_of_step_time": tot_ms / (1e3 * dt / args.steps)},

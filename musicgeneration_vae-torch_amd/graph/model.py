@@ -15,7 +15,7 @@ from graph.weights_initializer import weights_init
 
 
 import os
-OVERLAP_TRUNKS = os.environ.get("MGVAE_OVERLAP", "1") != "0"
+OVERLAP_TRUNKS = os.environ.get("MGVAE_OVERLAP", "1") != "0" and os.environ.get("MGVAE_SERIAL", "0") == "0"
 
 
 class Model(nn.Module):

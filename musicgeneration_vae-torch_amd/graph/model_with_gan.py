@@ -7,6 +7,7 @@ from graph.decoder import Decoder
 from graph.encoder import Encoder
 from graph.phrase_encoder import PhraseModel
 from graph.weights_initializer import weights_init
+from graph import model as _plain
 
 
 class Model(nn.Module):
@@ -26,14 +27,20 @@ class Model(nn.Module):
         b = note.shape[0]
         return zz[:b], zz[b:]
 
+    # phrase trunk on a side stream beside the bar trunk (graph/model.py::Model.encode_phrase)
+    encode_phrase = _plain.Model.encode_phrase
+    join_phrase = _plain.Model.join_phrase
+
     def forward(self, note, pre_note, phrase, position, is_note=True):
-        phrase_feature = self.phrase_encoder(phrase)
+        phrase_feature = self.encode_phrase(phrase)
         if is_note:
             z, pre_z = self.encode_pair(note, pre_note)
+            self.join_phrase()
             gen = self.decoder(z, pre_z, phrase_feature, position)
             fake = torch.gt(gen.detach(), 0.3).float()
             return gen, z, pre_z, phrase_feature, self.encoder(fake)
         pre_z = self.encoder(pre_note)
+        self.join_phrase()
         gen = self.decoder(note, pre_z, phrase_feature, position)
         fake = torch.gt(gen.detach(), 0.3).float()
         return gen, self.encoder(fake)

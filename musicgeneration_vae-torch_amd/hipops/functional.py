@@ -150,10 +150,11 @@ def _conv_bwd_data(d, y, w, b, x, mask=None):
 
 # ---- side streams: independent work of one backward node (the weight gradient vs the data gradient of a conv) and
 # independent branches of the model run concurrently; under-filled launches (small maps, tiny GEMMs) then overlap.
-FORK_WGRAD = _os.environ.get("MGVAE_FORK_WGRAD", "1") != "0"
+SERIAL = _os.environ.get("MGVAE_SERIAL", "0") != "0"       # one stream only: per-kernel profiles without co-running kernels
+FORK_WGRAD = _os.environ.get("MGVAE_FORK_WGRAD", "1") != "0" and not SERIAL
 _side_streams = {}      # (device index, id of the stream forked from) -> side stream
 _used_sides = {}        # streams with work of the running backward pass, to be joined by _join_sides
-_join_queued = [False]
+_join_queued = [-1]      # id of the autograd graph task that already has the join callback queued
 
 
 def side_stream_of(cur, slot=0):
@@ -175,7 +176,7 @@ def _join_sides(slot=None):
             cur.wait_stream(st)
             del _used_sides[key]
     if slot is None:
-        _join_queued[0] = False
+        _join_queued[0] = -1
 
 
 def join_side_streams(slot=None):
@@ -197,9 +198,10 @@ class _forked:
             if t is not None:
                 t.record_stream(side)
         _used_sides[id(side)] = (side, self.slot)
-        if not _join_queued[0] and torch._C._current_graph_task_id() != -1:
+        task = torch._C._current_graph_task_id()
+        if task != -1 and _join_queued[0] != task:      # once per backward pass (keyed by task: survives an aborted pass)
             torch.autograd.Variable._execution_engine.queue_callback(_join_sides)
-            _join_queued[0] = True
+            _join_queued[0] = task
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return side
@@ -208,7 +210,7 @@ class _forked:
         return self.ctx.__exit__(*a)
 
 
-FORK_BRANCHES = _os.environ.get("MGVAE_FORK_BRANCHES", "0") != "0"   # measured: -0.5 % (decoder branches, z-losses) -> off
+FORK_BRANCHES = _os.environ.get("MGVAE_FORK_BRANCHES", "0") != "0" and not SERIAL   # measured: -0.5 % (decoder branches, z-losses) -> off
 
 
 class forked_branch:

@@ -62,7 +62,7 @@ class PretrainStep:
                 return loss + 2.0 * DLoss.constant(self.zb(zz).view(-1), 1.0)
             return loss + DLoss.constant(self.zb(z).view(-1), 1.0) + DLoss.constant(self.zb(pre_z).view(-1), 1.0)
 
-        if hasattr(gen_m, "encode_pair") and not getattr(gen_m, "use_refiner", False) and hasattr(gen_m, "join_phrase"):
+        if type(gen_m).__module__ == "graph.model" and not getattr(gen_m, "use_refiner", False):
             pf = gen_m.encode_phrase(phrase)
             z, pre_z = gen_m.encode_pair(note, pre_note)
             gen_m.join_phrase()

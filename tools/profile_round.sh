@@ -12,6 +12,7 @@ cd $R
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { tail -5 $O/${TAG}_bench.err; exit 1; }
 echo "bench done"; tail -c 400 $O/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_prof.log 2>&1 || { echo "rocprof failed"; tail -5 $O/${TAG}_prof.log; exit 1; }
+# per-kernel statistics with the side streams off (MGVAE_SERIAL=1): every kernel alone on the chip, as in the roofline step of bench.py
+MGVAE_SERIAL=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_prof.log 2>&1 || { echo "rocprof failed"; tail -5 $O/${TAG}_prof.log; exit 1; }
 echo "kernel stats done"
-cd $R && bash tools/pmc_collect.sh ${TAG}_pmc
+cd $R && MGVAE_SERIAL=1 bash tools/pmc_collect.sh ${TAG}_pmc
