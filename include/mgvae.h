@@ -237,6 +237,11 @@ int mgvae_reparam_kl_bwd(const float* mean, const float* logvar, const float* ep
  * hyper (device, 4 floats): lr/bias_correction1, sqrt(bias_correction2), beta1, beta2.
  * One launch updates a whole flat parameter buffer; grad_scale multiplies g first
  * (1/world_size after an all-reduce(sum)).                                             */
+/* Input pipeline (reference data/bar_dataset.py:20-25 + agent make_batch, barGen2.py:128-135, ship fp32 rolls: 138 KB per
+ * sample).  Rolls are {0,1}: the host ships them bit-packed (LSB first) and the device expands them to fp32:
+ * out[i] = (packed[i >> 3] >> (i & 7)) & 1, i < nbits.  `out` 16-byte aligned. */
+int mgvae_unpack_bits(const unsigned char* packed, float* out, size_t nbits, void* stream);
+
 int mgvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                     float eps, float grad_scale, void* stream);
 

@@ -27,7 +27,7 @@ from metrics import AverageMeter
 class BarGen(AgentBase):
     def __init__(self, config):
         super().__init__(config)
-        self.dataset = NoteDataset(self.config.root_path, self.config)
+        self.dataset = self.make_dataset()
         self.dataloader = self.make_loader(self.dataset)
 
         self.generator = Model().to(self.device)

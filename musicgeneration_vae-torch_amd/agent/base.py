@@ -149,8 +149,19 @@ class AgentBase(object):
             logger.addHandler(fh)
         return logger
 
+    def make_dataset(self):
+        """NoteDataset (the reference's per-sample npz files) or, with ``config.packed_data_file``, the bit-packed one"""
+        if getattr(self.config, "packed_data_file", None):
+            from data.bar_dataset import PackedNoteDataset
+            return PackedNoteDataset(self.config.root_path, self.config)
+        from data.bar_dataset import NoteDataset
+        return NoteDataset(self.config.root_path, self.config)
+
     def make_batch(self, samples):
         cat = lambda k: np.concatenate([s[k] for s in samples], axis=0)
+        if "note_bits" in samples[0]:           # packed: ship the bits, expand them in to_device
+            return (torch.from_numpy(cat("note_bits")), torch.from_numpy(cat("pre_note_bits")),
+                    torch.from_numpy(cat("pre_phrase_bits")), torch.from_numpy(cat("position").astype(np.int64)))
         return (torch.tensor(cat("note"), dtype=torch.float), torch.tensor(cat("pre_note"), dtype=torch.float),
                 torch.tensor(cat("pre_phrase"), dtype=torch.float), torch.tensor(cat("position"), dtype=torch.long))
 
@@ -181,7 +192,12 @@ class AgentBase(object):
 
     def to_device(self, *tensors):
         nb = bool(self.config.async_loading)
-        return tuple(t.to(self.device, non_blocking=nb) for t in tensors)
+        out = tuple(t.to(self.device, non_blocking=nb) for t in tensors)
+        if out[0].dtype == torch.uint8:         # bit-packed rolls: expand to fp32 on the device
+            b = out[0].shape[0]
+            out = (HF.unpack_bits(out[0], (b, 1, 96, 60)), HF.unpack_bits(out[1], (b, 1, 96, 60)),
+                   HF.unpack_bits(out[2], (b, 1, 384, 60)), out[3])
+        return out
 
     def run(self):
         try:

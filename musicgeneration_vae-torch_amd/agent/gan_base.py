@@ -34,7 +34,7 @@ class GanAgentBase(AgentBase):
         self.flag_gan = False
         self.train_count = 0
         self.batch_size = self.config.batch_size + self.batch_bonus
-        self.dataset = NoteDataset(self.config.root_path, self.config)
+        self.dataset = self.make_dataset()
         self.dataloader = self.make_loader(self.dataset)
         self.generator = Model().to(self.device)
         self.discriminator = BarDiscriminator().to(self.device)

@@ -434,6 +434,36 @@ extern "C" int mgvae_reparam_kl_bwd(const float* mean, const float* logvar, cons
     return MGVAE_OK;
 }
 
+// ------------------------------------------------------------------ bit-packed piano rolls -> fp32
+// A bar is 96x60 = 5760 {0,1} cells: 720 bytes packed (LSB first, numpy packbits bitorder='little') against 23 KB as
+// fp32.  The host ships the packed rows; this kernel expands them on the device: one thread per output byte-group
+// of 8 cells (two float4 stores).
+__global__ __launch_bounds__(256) void unpack_bits_kernel(const unsigned char* __restrict__ packed, float* __restrict__ out,
+                                                          size_t nbytes, size_t nbits) {
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nbytes; b += (size_t)gridDim.x * 256) {
+        const unsigned v = packed[b];
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (float)((v >> k) & 1u);
+        const size_t o = b * 8;
+        if (o + 8 <= nbits) {
+            float4* o4 = reinterpret_cast<float4*>(out + o);
+            o4[0] = make_float4(f[0], f[1], f[2], f[3]);
+            o4[1] = make_float4(f[4], f[5], f[6], f[7]);
+        } else {
+            for (int k = 0; k < 8 && o + k < nbits; ++k) out[o + k] = f[k];
+        }
+    }
+}
+
+extern "C" int mgvae_unpack_bits(const unsigned char* packed, float* out, size_t nbits, void* stream) {
+    if (!packed || !out || nbits == 0 || ((uintptr_t)out & 15)) return MGVAE_EINVAL;
+    const size_t nbytes = (nbits + 7) / 8;
+    hipLaunchKernelGGL(unpack_bits_kernel, dim3(grid_for(nbytes, 4096)), dim3(256), 0, as_stream(stream), packed, out, nbytes, nbits);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
 // ------------------------------------------------------------------ fused flat Adam
 // 7 streams of n floats (read p,g,m,v; write p,m,v): pure HBM traffic, float4 per lane.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -860,6 +860,18 @@ def randn(shape, sigma=1.0, device="cuda", out=None):
     return out
 
 
+def unpack_bits(packed, shape):
+    """bit-packed {0,1} rolls (uint8 device tensor, LSB first) -> fp32 tensor of ``shape`` (input pipeline)"""
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("unpack_bits: expected a uint8 ROCm device tensor")
+    packed = packed.contiguous()
+    out = torch.empty(shape, device=packed.device, dtype=torch.float32)
+    if out.numel() > packed.numel() * 8:
+        raise RuntimeError("unpack_bits: %d cells do not fit %d packed bytes" % (out.numel(), packed.numel()))
+    nat.check(nat.lib().mgvae_unpack_bits(_p(packed), _p(out), out.numel(), _s()), "unpack_bits")
+    return out
+
+
 # ============================================================================== losses
 _prior_cache = {}
 

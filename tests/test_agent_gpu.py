@@ -160,3 +160,39 @@ def test_graph_sampler_replays_the_eager_loop():
         HF.manual_seed(11)
         again = gs.sample(3)                         # replays are repeatable
         assert float((again != got).float().mean()) < 2e-3
+
+
+def test_packed_dataset_feeds_the_same_batches(tmp_path):
+    """bit-packed input pipeline: the agent with ``config.packed_data_file`` sees exactly the batches of the
+    reference-format dataset (bits shipped, expanded on the GPU by mgvae_unpack_bits) and trains on them"""
+    import __graft_entry__ as g
+    g.build()
+    from config import Config
+    from data.bar_dataset import pack_dataset
+    from agent.barGen2 import BarGen
+    from hipops import functional as HF
+    root = str(tmp_path)
+    _make_dataset(root, n_files=8, per_file=1)      # one sample per file: batch_size then means the same in both datasets
+    pack_dataset(os.path.join(root, "data", "dataset"), os.path.join(root, "data", "packed.npz"))
+    x = (np.random.default_rng(0).random((3, 5760)) < 0.1)
+    bits = torch.from_numpy(np.packbits(x.astype(np.uint8), axis=1, bitorder="little")).cuda()
+    assert torch.equal(HF.unpack_bits(bits, (3, 1, 96, 60)).cpu().view(3, -1), torch.from_numpy(x.astype(np.float32)))
+
+    def cfg(packed):
+        class Cfg(Config):
+            root_path = root
+            batch_size = 4
+            epoch = 1
+            pretraining_step_size = 5
+            seed = 11
+            packed_data_file = "data/packed.npz" if packed else None
+            log_file = os.path.join(root, "train_epoch.log")
+        return Cfg()
+
+    a, b = BarGen(cfg(False)), BarGen(cfg(True))
+    for ba, bb in zip(a.dataloader, b.dataloader):
+        ta, tb = a.to_device(*ba), b.to_device(*bb)
+        for u, v in zip(ta, tb):
+            assert u.dtype == v.dtype and torch.equal(u, v)
+    b.run()
+    assert b.epoch == 1
