@@ -154,6 +154,8 @@ SERIAL = _os.environ.get("MGVAE_SERIAL", "0") != "0"       # one stream only: pe
 FORK_WGRAD = _os.environ.get("MGVAE_FORK_WGRAD", "1") != "0" and not SERIAL
 _side_streams = {}      # (device index, id of the stream forked from) -> side stream
 _used_sides = {}        # streams with work of the running backward pass, to be joined by _join_sides
+WGRAD_STREAMS = int(_os.environ.get("MGVAE_WGRAD_STREAMS", "1"))   # side streams the weight gradients rotate over
+_wgrad_rr = [0]
 _join_queued = [-1]      # id of the autograd graph task that already has the join callback queued
 
 
@@ -286,7 +288,8 @@ class _ConvFn(torch.autograd.Function):
                 nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Cy, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
 
         if FORK_WGRAD and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
-            with _forked(x, dy):          # the weight gradient runs beside the data gradient below
+            _wgrad_rr[0] += 1
+            with _forked(x, dy, slot=2 + _wgrad_rr[0] % WGRAD_STREAMS):   # the weight gradient runs beside the data gradient below
                 weight_grads()
         else:
             weight_grads()
@@ -365,7 +368,8 @@ class _ConvTFn(torch.autograd.Function):
                 nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Co, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
 
         if FORK_WGRAD and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
-            with _forked(x, dy):
+            _wgrad_rr[0] += 1
+            with _forked(x, dy, slot=2 + _wgrad_rr[0] % WGRAD_STREAMS):
                 weight_grads()
         else:
             weight_grads()
