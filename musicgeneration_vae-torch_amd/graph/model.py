@@ -48,7 +48,9 @@ class Model(nn.Module):
             return self.phrase_encoder(phrase)
         cur = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
+            from hipops import functional as HF
             self._side = torch.cuda.Stream()
+            HF.register_trunk_stream(self._side)      # joined at the end of every backward pass / before an all-reduce
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             pf = self.phrase_encoder(phrase)

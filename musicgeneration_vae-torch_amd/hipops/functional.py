@@ -168,10 +168,25 @@ def side_stream_of(cur, slot=0):
     return st
 
 
+_trunk_streams = []      # long-lived side streams that carry whole branches of the model (Model.encode_phrase)
+
+
+def register_trunk_stream(st):
+    """a stream on which a module runs a whole branch: autograd replays that branch's backward there, and its
+    weight-like gradients are written by our kernels (no AccumulateGrad node, so the engine does not sync it back):
+    the end-of-backward join and the gradient reducer wait for it explicitly"""
+    if all(st is not t for t in _trunk_streams):
+        _trunk_streams.append(st)
+
+
 def _join_sides(slot=None):
     """make the caller's stream wait for every side stream used since the last join (end of a backward pass);
     ``slot``: only the side streams of that slot"""
     cur = torch.cuda.current_stream()
+    if slot is None:
+        for st in _trunk_streams:
+            if st.device == cur.device and st.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(st)
     for key in list(_used_sides):
         st, sl = _used_sides[key]
         if slot is None or sl == slot:
@@ -183,6 +198,14 @@ def _join_sides(slot=None):
 
 def join_side_streams(slot=None):
     _join_sides(slot)
+
+
+def _ensure_join_callback():
+    """queue the end-of-backward join once per backward pass (called from every conv backward)"""
+    task = torch._C._current_graph_task_id()
+    if task != -1 and _join_queued[0] != task:
+        torch.autograd.Variable._execution_engine.queue_callback(_join_sides)
+        _join_queued[0] = task
 
 
 class _forked:
@@ -200,10 +223,7 @@ class _forked:
             if t is not None:
                 t.record_stream(side)
         _used_sides[id(side)] = (side, self.slot)
-        task = torch._C._current_graph_task_id()
-        if task != -1 and _join_queued[0] != task:      # once per backward pass (keyed by task: survives an aborted pass)
-            torch.autograd.Variable._execution_engine.queue_callback(_join_sides)
-            _join_queued[0] = task
+        _ensure_join_callback()      # once per backward pass (keyed by task: survives an aborted pass)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return side
@@ -275,6 +295,8 @@ class _ConvFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, Cx, H, W, Cy, OH, OW, k, s, p, xct, act, slope = ctx.geom
         L = nat.lib()
+        if _trunk_streams or _used_sides:
+            _ensure_join_callback()
         if act != ACT_NONE and not ctx.defer:
             dy = _act_bwd(y, dy, act, slope)
         dy, dct = _sliceable(dy)
