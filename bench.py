@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="bars per GPU")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_bf16x3"],
                     help="matrix-operand precision of the conv kernels; f32 is BASELINE.json's metric config (configs[1]), "
                          "bf16 (operands bf16, accumulate fp32, tensors and master weights fp32) is configs[2]/[3]'s")
     ap.add_argument("--graph", action="store_true",

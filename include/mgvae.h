@@ -81,7 +81,10 @@ int mgvae_conv2d_bwd_data_tw(const MgvaeConvDesc* d, const float* y, const float
  * 3-4 ("bf16 compute / fp32 master weights"): tensors stay fp32 in HBM, operands are rounded to bf16 (RNE) while
  * being staged, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16.  Thin (K<=16) and skinny (Linear) paths
  * stay fp32. */
-enum { MGVAE_COMPUTE_F32 = 0, MGVAE_COMPUTE_BF16 = 1 };
+/* F32_BF16X3 (opt-in): fp32-ACCURATE products on the bf16 matrix pipe -- every fp32 operand is split exactly into three
+ * bf16 terms (8+8+8 mantissa bits) and a product is the six bf16 MFMAs whose terms are >= 2^-16 relative; bf16*bf16
+ * is exact in the fp32 accumulator and the dropped terms are <= 2^-24 relative.  6/16 of the fp32 matrix-pipe time. */
+enum { MGVAE_COMPUTE_F32 = 0, MGVAE_COMPUTE_BF16 = 1, MGVAE_COMPUTE_F32_BF16X3 = 2 };
 int mgvae_set_compute_dtype(int dtype);
 int mgvae_get_compute_dtype(void);
 

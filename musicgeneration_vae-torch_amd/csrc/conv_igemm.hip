@@ -49,7 +49,7 @@ struct IgemmP {
     const float* mask;
     int mask_ctot, mask_coff, mask_act;
     float mask_slope;
-    int bf16;           // 1: igemm_bf16_kernel (bf16 operands, fp32 accumulate)
+    int bf16;           // 1: igemm_bf16_kernel with bf16 operands; 3: with three-term bf16 splits (fp32 accuracy)
 };
 
 // Operand loads go through buffer descriptors: a masked element gets the offset 0xFFFFFFFF, which the
@@ -439,7 +439,24 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int MODE, int TI, int TJ>
+// NS = 1: plain bf16 operands.  NS = 3: every fp32 operand is split EXACTLY into three bf16 terms x = hi + mid + lo
+// (8 + 8 + 8 mantissa bits) kept as three LDS planes, and a product is the six bf16 MFMAs whose terms are >= 2^-16
+// relative: hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid.  bf16 x bf16 is exact in the fp32 accumulator, the
+// dropped terms are <= 2^-24 relative, so the result has fp32 accuracy at 6/16 of the fp32 matrix-pipe time.
+// Truncating split (3 VALU ops + 2 subtractions, all exact): hi = top 8 mantissa bits, mid = the next 8, lo = the rest;
+// every term is a bf16 value held in a float whose low 16 bits are zero.
+__device__ __forceinline__ void split3(float x, float& hi, float& mid, float& lo) {
+    hi = __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+    const float r1 = x - hi;              // exact, <= 16 significant bits
+    mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    lo = r1 - mid;                        // exact, <= 8 significant bits: a bf16 value
+}
+// two floats that ARE bf16 values -> one packed dword (low half = first): a byte permute, no rounding needed
+__device__ __forceinline__ unsigned pack_bf16_exact(float lo_elem, float hi_elem) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+
+template <int MODE, int TI, int TJ, int NS>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     constexpr int IT = 64 * TI, JT = 64 * TJ;
     constexpr int BKc = 32, LDB = BKc + 8;
@@ -449,9 +466,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     constexpr int NA = IT * BKc / 256, NB = JT * BKc / 256;   // values per thread and K tile
     constexpr int NA2 = NA / 2, NB2 = NB / 2;                  // k pairs per thread (k-mapped loaders)
 
-    __shared__ __attribute__((aligned(16))) u16_t lds[2 * (A_ELEMS + B_ELEMS)];
+    __shared__ __attribute__((aligned(16))) u16_t lds[2 * NS * (A_ELEMS + B_ELEMS)];   // [buffer][plane] per operand
     u16_t* As0 = lds;
-    u16_t* Bs0 = lds + 2 * A_ELEMS;
+    u16_t* Bs0 = lds + 2 * NS * A_ELEMS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -621,32 +638,43 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         }
     };
 
+    // plane s of a register array: s = 0 the value rounded to bf16 (NS = 1) or its hi / mid / lo term (NS = 3)
+    auto term = [&](float x, int s) -> float {
+        if constexpr (NS == 1) { return x; }
+        else { float hi, mid, lo; split3(x, hi, mid, lo); return s == 0 ? hi : (s == 1 ? mid : lo); }
+    };
+    auto pk = [&](float a0, float a1) -> unsigned {
+        if constexpr (NS == 1) return pack_bf16(a0, a1); else return pack_bf16_exact(a0, a1);
+    };
     auto store_tile = [&](int buf) {
-        u16_t* As = As0 + buf * A_ELEMS;
-        u16_t* Bs = Bs0 + buf * B_ELEMS;
-        if constexpr (A_K) {
 #pragma unroll
-            for (int r = 0; r < NA2; ++r)
-                *reinterpret_cast<unsigned*>(As + (rr + 16 * r) * LDB + kl2) = pack_bf16(ra[2 * r], ra[2 * r + 1]);
-        } else {
-            u16_t* row = As + (ic * 64 + lane) * LDB + ikr0;
+        for (int s = 0; s < NS; ++s) {
+            u16_t* As = As0 + (buf * NS + s) * A_ELEMS;
+            u16_t* Bs = Bs0 + (buf * NS + s) * B_ELEMS;
+            if constexpr (A_K) {
 #pragma unroll
-            for (int q = 0; q < NA / 8; ++q)
-                *reinterpret_cast<uint4*>(row + 8 * q) =
-                    make_uint4(pack_bf16(ra[8 * q], ra[8 * q + 1]), pack_bf16(ra[8 * q + 2], ra[8 * q + 3]),
-                               pack_bf16(ra[8 * q + 4], ra[8 * q + 5]), pack_bf16(ra[8 * q + 6], ra[8 * q + 7]));
-        }
-        if constexpr (B_K) {
+                for (int r = 0; r < NA2; ++r)
+                    *reinterpret_cast<unsigned*>(As + (rr + 16 * r) * LDB + kl2) = pk(term(ra[2 * r], s), term(ra[2 * r + 1], s));
+            } else {
+                u16_t* row = As + (ic * 64 + lane) * LDB + ikr0;
 #pragma unroll
-            for (int r = 0; r < NB2; ++r)
-                *reinterpret_cast<unsigned*>(Bs + (rr + 16 * r) * LDB + kl2) = pack_bf16(rb[2 * r], rb[2 * r + 1]);
-        } else {
-            u16_t* row = Bs + (jc * 64 + lane) * LDB + jkr0;
+                for (int q = 0; q < NA / 8; ++q)
+                    *reinterpret_cast<uint4*>(row + 8 * q) =
+                        make_uint4(pk(term(ra[8 * q], s), term(ra[8 * q + 1], s)), pk(term(ra[8 * q + 2], s), term(ra[8 * q + 3], s)),
+                                   pk(term(ra[8 * q + 4], s), term(ra[8 * q + 5], s)), pk(term(ra[8 * q + 6], s), term(ra[8 * q + 7], s)));
+            }
+            if constexpr (B_K) {
 #pragma unroll
-            for (int q = 0; q < NB / 8; ++q)
-                *reinterpret_cast<uint4*>(row + 8 * q) =
-                    make_uint4(pack_bf16(rb[8 * q], rb[8 * q + 1]), pack_bf16(rb[8 * q + 2], rb[8 * q + 3]),
-                               pack_bf16(rb[8 * q + 4], rb[8 * q + 5]), pack_bf16(rb[8 * q + 6], rb[8 * q + 7]));
+                for (int r = 0; r < NB2; ++r)
+                    *reinterpret_cast<unsigned*>(Bs + (rr + 16 * r) * LDB + kl2) = pk(term(rb[2 * r], s), term(rb[2 * r + 1], s));
+            } else {
+                u16_t* row = Bs + (jc * 64 + lane) * LDB + jkr0;
+#pragma unroll
+                for (int q = 0; q < NB / 8; ++q)
+                    *reinterpret_cast<uint4*>(row + 8 * q) =
+                        make_uint4(pk(term(rb[8 * q], s), term(rb[8 * q + 1], s)), pk(term(rb[8 * q + 2], s), term(rb[8 * q + 3], s)),
+                                   pk(term(rb[8 * q + 4], s), term(rb[8 * q + 5], s)), pk(term(rb[8 * q + 6], s), term(rb[8 * q + 7], s)));
+            }
         }
     };
 
@@ -666,22 +694,33 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
             if (t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
-            const u16_t* As = As0 + buf * A_ELEMS;
-            const u16_t* Bs = Bs0 + buf * B_ELEMS;
+            const u16_t* As = As0 + buf * NS * A_ELEMS;
+            const u16_t* Bs = Bs0 + buf * NS * B_ELEMS;
 #pragma unroll
             for (int ks = 0; ks < BKc / 16; ++ks) {
-                bf16x8_t a[TI], b[TJ];
+                bf16x8_t a[NS][TI], b[NS][TJ];
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti)
-                    a[ti] = *reinterpret_cast<const bf16x8_t*>(As + (wi * 32 * TI + ti * 32 + l31) * LDB + ks * 16 + h * 8);
+                for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int tj = 0; tj < TJ; ++tj)
-                    b[tj] = *reinterpret_cast<const bf16x8_t*>(Bs + (wj * 32 * TJ + tj * 32 + l31) * LDB + ks * 16 + h * 8);
-#pragma unroll
-                for (int ti = 0; ti < TI; ++ti)
+                    for (int ti = 0; ti < TI; ++ti)
+                        a[s][ti] = *reinterpret_cast<const bf16x8_t*>(As + s * A_ELEMS + (wi * 32 * TI + ti * 32 + l31) * LDB + ks * 16 + h * 8);
 #pragma unroll
                     for (int tj = 0; tj < TJ; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+                        b[s][tj] = *reinterpret_cast<const bf16x8_t*>(Bs + s * B_ELEMS + (wj * 32 * TJ + tj * 32 + l31) * LDB + ks * 16 + h * 8);
+                }
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TJ; ++tj) {
+                        if constexpr (NS == 3) {      // small terms first
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ti], b[1][tj], acc[ti][tj], 0, 0, 0);
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ti], b[2][tj], acc[ti][tj], 0, 0, 0);
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][ti], b[0][tj], acc[ti][tj], 0, 0, 0);
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ti], b[1][tj], acc[ti][tj], 0, 0, 0);
+                            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][ti], b[0][tj], acc[ti][tj], 0, 0, 0);
+                        }
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][ti], b[0][tj], acc[ti][tj], 0, 0, 0);
+                    }
             }
             if (t + 1 < nt) store_tile(buf ^ 1);
             __syncthreads();
@@ -982,11 +1021,14 @@ static int validate(const MgvaeConvDesc* d) {
 // matrix-operand precision of the tiled conv kernels (process-wide; the thin / skinny paths always run fp32)
 static std::atomic<int> g_compute_bf16{0};
 extern "C" int mgvae_set_compute_dtype(int dtype) {
-    if (dtype != MGVAE_COMPUTE_F32 && dtype != MGVAE_COMPUTE_BF16) return MGVAE_EINVAL;
-    g_compute_bf16.store(dtype == MGVAE_COMPUTE_BF16 ? 1 : 0);
+    if (dtype != MGVAE_COMPUTE_F32 && dtype != MGVAE_COMPUTE_BF16 && dtype != MGVAE_COMPUTE_F32_BF16X3) return MGVAE_EINVAL;
+    g_compute_bf16.store(dtype == MGVAE_COMPUTE_BF16 ? 1 : (dtype == MGVAE_COMPUTE_F32_BF16X3 ? 3 : 0));
     return MGVAE_OK;
 }
-extern "C" int mgvae_get_compute_dtype(void) { return g_compute_bf16.load() ? MGVAE_COMPUTE_BF16 : MGVAE_COMPUTE_F32; }
+extern "C" int mgvae_get_compute_dtype(void) {
+    const int v = g_compute_bf16.load();
+    return v == 1 ? MGVAE_COMPUTE_BF16 : (v == 3 ? MGVAE_COMPUTE_F32_BF16X3 : MGVAE_COMPUTE_F32);
+}
 
 static IgemmP make_params(const MgvaeConvDesc* d) {
     IgemmP p{};
@@ -1115,12 +1157,21 @@ static void act_slice(float* t, int N, int C, long P, int ctot, int act, float s
 
 template <int MODE>
 static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
-    if (p.bf16) {
+    if (p.bf16 == 1) {
         switch (tile) {
-            case 0: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, p); break;
-            case 1: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 2>), grid, dim3(256), 0, s, p); break;
-            case 2: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 1>), grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 1>), grid, dim3(256), 0, s, p); break;
+            case 0: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 2, 1>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 2, 1>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 1, 1>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 1, 1>), grid, dim3(256), 0, s, p); break;
+        }
+        MGVAE_CHECK_LAUNCH();
+        return MGVAE_OK;
+    }
+    if (p.bf16 == 3) {      // three-term split: the 128x128 tile would need 120 KB of LDS -> exec_* map it to 128x64
+        switch (tile) {
+            case 2: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 2, 1, 3>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 2, 3>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((igemm_bf16_kernel<MODE, 1, 1, 3>), grid, dim3(256), 0, s, p); break;
         }
         MGVAE_CHECK_LAUNCH();
         return MGVAE_OK;
@@ -1179,6 +1230,7 @@ extern "C" int mgvae_prof_record_end(void* token, void* stream) {
 // ---- launch helpers: one function per mode that runs a given (tile, split) configuration -----------
 
 static int exec_fwd(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit, hipStream_t s) {
+    if (p.bf16 == 3 && tile == 0) tile = 2;        // no 128x128 tile in the three-term mode (LDS)
     const long I = d->Cy, J = (long)d->N * d->OH * d->OW;
     const long P = (long)d->OH * d->OW;
     float* y = p.out + (size_t)d->y_coff * P;          // first channel of the written slice
@@ -1191,6 +1243,7 @@ static int exec_fwd(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit, hipS
 }
 
 static int exec_bwd_data(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit, hipStream_t s) {
+    if (p.bf16 == 3 && tile == 0) tile = 2;
     const int Z = d->SH * d->SW;
     const long I = d->Cx, J = (long)d->N * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);   // largest phase
     const long HW = (long)d->H * d->W;
@@ -1206,6 +1259,7 @@ static int exec_bwd_data(const MgvaeConvDesc* d, IgemmP p, int tile, int ksplit,
 }
 
 static int exec_bwd_weight(const MgvaeConvDesc* d, IgemmP p, int tile, long splits, hipStream_t s) {
+    if (p.bf16 == 3 && tile == 0) tile = 2;
     const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
     if (splits < 1) splits = 1;
     long kchunk = cdiv(M, splits);

@@ -97,12 +97,12 @@ def _mask(t, act, slope):
 def set_compute_dtype(name):
     """"f32" (default) or "bf16": matrix-operand precision of the tiled conv kernels (mgvae_set_compute_dtype):
     bf16 = BASELINE.json configs 3-4, bf16 operands / fp32 accumulate / fp32 tensors and master weights"""
-    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(name).lower()]
+    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f32_bf16x3": 2}[str(name).lower()]
     nat.check(nat.lib().mgvae_set_compute_dtype(code), "set_compute_dtype")
 
 
 def get_compute_dtype():
-    return "bf16" if nat.lib().mgvae_get_compute_dtype() == 1 else "f32"
+    return {0: "f32", 1: "bf16", 2: "f32_bf16x3"}[nat.lib().mgvae_get_compute_dtype()]
 
 
 def _conv_fwd(d, x, w, b, y, mask=None):

@@ -929,3 +929,34 @@ def test_graphed_train_step_matches_eager():
     gs2(*batch); m0 = gs2.masks[0].clone()
     gs2(*batch)
     assert not torch.equal(m0, gs2.masks[0]) and set(gs2.masks[0].unique().tolist()) <= {0.0, 1.0 / 0.7} | {float(torch.tensor(1.0 / 0.7, dtype=torch.float32))}
+
+
+@pytest.mark.parametrize("g", BF16_GEOMS, ids=lambda g: "x".join(map(str, g[:5])) + "k%dx%d" % g[5])
+def test_conv2d_f32_via_bf16x3(g):
+    """opt-in fp32-accurate mode on the bf16 matrix pipe (exact three-term operand split, six products): against the
+    fp64 reference it must be as close as the native fp32-MFMA kernels are -- same tolerance, UNROUNDED operands."""
+    N, Ci, H, W_, Co, k, s, p = g
+    hf = HF()
+    x = torch.randn(N, Ci, H, W_).relu_(); w = torch.randn(Co, Ci, *k) * 0.2 - 0.1
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=s, padding=p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    errs = {}
+    for mode in ("f32", "f32_bf16x3"):
+        hf.set_compute_dtype(mode)
+        try:
+            xd = x.to(dev).requires_grad_(True); wd = torch.nn.Parameter(w.to(dev))
+            y = hf.conv2d(xd, wd, None, s, p)
+            y.backward(dy.float().to(dev))
+            errs[mode] = [float((a.double().cpu() - b).abs().max() / b.abs().max()) for a, b in
+                          ((y, yr.detach()), (xd.grad, xr.grad), (wd.grad, wr.grad))]
+            if mode != "f32":
+                check("f32 via bf16x3 fwd %s" % (g,), y, yr)
+                check("f32 via bf16x3 dx %s" % (g,), xd.grad, xr.grad)
+                check("f32 via bf16x3 dw %s" % (g,), wd.grad, wr.grad)
+        finally:
+            hf.set_compute_dtype("f32")
+    # fp32 accuracy, not bf16 accuracy: within a small factor of the native kernel's own error (both ~1e-7..1e-6)
+    for e_split, e_native in zip(errs["f32_bf16x3"], errs["f32"]):
+        assert e_split <= max(4 * e_native, 2e-6), (errs, g)
