@@ -32,7 +32,9 @@ struct DcP {
     int tiles_per_img;                // G == 1: row tiles per image
     int CC, nchunk, Kp, Ipad, lda;    // channel chunking; Kp = padded CC*T; lda = Kp + 1
     int act; float slope;
+    unsigned src_bytes;               // extent of the source tensor (buffer descriptor: masked elements read as 0)
 };
+#define DC_MAXX 8                     // halo-tile elements per thread and chunk that the register prefetch can hold
 
 template <int TI, int TJ>
 __global__ __launch_bounds__(256) void dconv_kernel(const DcP p) {
@@ -96,28 +98,63 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DcP p) {
 
     const int KQ = p.Kp >> 2;                      // float4 per packed row
     const int nA4 = IT * KQ;
-    __syncthreads();
-
-    for (int ch = 0; ch < p.nchunk; ++ch) {
-        // ---- stage the weight tile (contiguous float4 stream) ----
+    const int nx = p.CC * p.plane;
+    // Register prefetch: the weight tile and the halo tile of chunk ch+1 are loaded from global memory while the
+    // MFMAs of chunk ch run; one LDS buffer is enough (a chunk is committed to LDS after the barrier that ends the
+    // previous chunk's MFMAs).  Per-thread counts are bounded by the planner (Kp <= 72, CC * plane <= MAXX * 256).
+    constexpr int MAXA4 = (IT * 18 + 255) / 256;
+    constexpr int MAXX = DC_MAXX;
+    float4 ra[MAXA4];
+    float rx[MAXX];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    __syncthreads();                               // goff / toff are in place
+    // the halo-tile elements this thread stages are the same in every chunk: decode them once
+    int xoff[MAXX], xc[MAXX];                      // source offset without the chunk's channel base (-1: padding), channel in chunk
+#pragma unroll
+    for (int m = 0; m < MAXX; ++m) {
+        const int e = tid + 256 * m;
+        const int ec = e < nx ? e : 0;
+        const int c = ec / p.plane, q = ec - c * p.plane;
+        const int o = goff[q];
+        xc[m] = c;
+        xoff[m] = (e < nx && o >= 0) ? c * HWs + o : -1;
+    }
+    auto prefetch = [&](int ch) {
         const float4* wsrc = reinterpret_cast<const float4*>(p.wp + ((size_t)ch * p.Ipad + i0) * p.Kp);
-        for (int e = tid; e < nA4; e += 256) {
-            const float4 v = wsrc[e];
-            const int row = e / KQ, col = (e - row * KQ) << 2;
-            float* d = As + row * p.lda + col;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+        for (int q = 0; q < MAXA4; ++q) {
+            const int e = tid + 256 * q;
+            ra[q] = wsrc[e < nA4 ? e : 0];             // contiguous float4 stream; the tail is loaded, not stored
         }
-        // ---- stage the source tile with halo ----
         const int c0 = ch * p.CC;
-        for (int c = 0; c < p.CC; ++c) {
-            const bool cok = (c0 + c) < p.Cs;
-            const float* sp = p.src + (size_t)(c0 + c) * HWs;
-            for (int q = tid; q < p.plane; q += 256) {
-                const int o = goff[q];
-                Xs[c * p.plane + q] = (cok && o >= 0) ? sp[o] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MAXX; ++m) {
+            const bool ok = (xoff[m] >= 0) & ((c0 + xc[m]) < p.Cs);
+            rx[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? (c0 * HWs + xoff[m]) * 4 : -1, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < MAXA4; ++q) {
+            const int e = tid + 256 * q;
+            if (e < nA4) {
+                const int row = e / KQ, col = (e - row * KQ) << 2;
+                float* d = As + row * p.lda + col;
+                d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
             }
         }
+#pragma unroll
+        for (int m = 0; m < MAXX; ++m) {
+            const int e = tid + 256 * m;
+            if (e < nx) Xs[e] = rx[m];
+        }
+    };
+    prefetch(0);
+
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+        commit();
         __syncthreads();
+        if (ch + 1 < p.nchunk) prefetch(ch + 1);
         // ---- MFMA over (tap, channel pair) ----
         for (int t = 0; t < p.T; ++t) {
             const int to = toff[t];
@@ -277,8 +314,13 @@ static bool make_plan(const MgvaeConvDesc* d, int mode, int ph, Plan& P) {
         const int kp = ((c * k.T + 3) / 4) * 4;
         return (size_t)4 * ((size_t)IT * (kp + 1) + (size_t)c * k.plane + k.plane);
     };
-    while (cc > 2 && lds_bytes(cc) > 60 * 1024) cc -= 2;
-    if (lds_bytes(cc) > 60 * 1024) return false;
+    while (cc > 2 && (lds_bytes(cc) > 60 * 1024 || (long)cc * k.plane > DC_MAXX * 256)) cc -= 2;
+    if (lds_bytes(cc) > 60 * 1024 || (long)cc * k.plane > DC_MAXX * 256 || ((cc * k.T + 3) / 4) * 4 > 72) return false;
+    {
+        const size_t sb = (size_t)k.N * k.s_ctot * k.SRH * k.SRW * 4;
+        if (sb >= ((size_t)1 << 32)) return false;
+        k.src_bytes = (unsigned)sb;
+    }
     k.CC = cc; k.nchunk = cdiv(k.Cs, cc); k.Kp = ((cc * k.T + 3) / 4) * 4; k.lda = k.Kp + 1;
     k.Ipad = cdiv(k.Itot, IT) * IT;
     P.lds = lds_bytes(cc);

@@ -83,8 +83,44 @@ def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
 
 
 USE_TRANSPOSED_W = True   # data-gradient / transposed-conv kernels read a [Cy][KK][Cx] copy of the weight
-USE_DIRECT = False  # direct (halo-tile, packed-weight) conv kernels; False = implicit-GEMM fallback only
 import os as _os
+# direct (halo-tile, packed-weight, register-prefetched) conv kernels vs the implicit GEMM: MGVAE_DIRECT=0 (default)
+# implicit GEMM only, 1 = direct wherever supported, auto = time both the first time a geometry is seen and keep the
+# faster.  Back to back the direct kernel wins the large-map 3x3 layers (100-107 vs 88-98 TFLOP/s) and loses the rest;
+# in the step "auto" moves 11 launches and the step time does not change (27.5 ms either way), so it stays opt-in.
+USE_DIRECT = {"0": False, "1": True, "auto": "auto"}.get(_os.environ.get("MGVAE_DIRECT", "0"), False)
+_impl_choice = {}
+
+
+def _direct_candidate(d):
+    """"auto" only considers the direct kernel where it can win: 3x3 / 4x4-class windows on maps of >= 128 pixels,
+    fp32 operands (True tries it wherever the geometry is supported)"""
+    if USE_DIRECT is True:
+        return True
+    return d.KH * d.KW >= 9 and d.OH * d.OW >= 128 and d.H * d.W >= 128 and get_compute_dtype() == "f32"
+
+
+def _direct_wins(mode, d, run_igemm, run_direct):
+    """time both implementations once per (mode, geometry) and remember the faster"""
+    key = (mode, d.N, d.Cx, d.H, d.W, d.Cy, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW, d.x_ctot, d.y_ctot)
+    c = _impl_choice.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        times = []
+        for fn in (run_igemm, run_direct):
+            fn()                                   # warm-up (also lets the implicit GEMM autotune itself)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(); fn()
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        c = times[1] < 0.97 * times[0]
+        _impl_choice[key] = c
+    return c
+
+
 DEFER_ACT_GRAD = _os.environ.get("MGVAE_DEFER_ACT", "1") != "0"   # fold act' into the consumer's data gradient
 
 
@@ -113,13 +149,22 @@ def _conv_fwd(d, x, w, b, y, mask=None):
         m, keep = _mask(*mask)
         nat.check(L.mgvae_conv2d_fwd_masked(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), ctypes.byref(m), _s()), "conv2d_fwd_masked")
         return
-    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 0) if USE_DIRECT else 0
-    if n:
+    def igemm():
+        nat.check(L.mgvae_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv2d_fwd")
+
+    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 0) if (USE_DIRECT and _direct_candidate(d)) else 0
+    if not n:
+        return igemm()
+
+    def direct():
         wp = torch.empty((n,), device=w.device, dtype=torch.float32)
         nat.check(L.mgvae_conv_pack(ctypes.byref(d), 0, _p(w), _p(wp), _s()), "conv_pack")
         nat.check(L.mgvae_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(wp), _p(b), _p(y), _s()), "conv2d_fwd_packed")
+
+    if USE_DIRECT is True or _direct_wins(0, d, igemm, direct):
+        direct()
     else:
-        nat.check(L.mgvae_conv2d_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _s()), "conv2d_fwd")
+        igemm()
 
 
 def _conv_bwd_data(d, y, w, b, x, mask=None):
@@ -135,17 +180,27 @@ def _conv_bwd_data(d, y, w, b, x, mask=None):
         nat.check(L.mgvae_conv2d_bwd_data_masked(ctypes.byref(d), _p(y), _p(w), 1 if tw else 0, _p(b), _p(x), ctypes.byref(m), _s()),
                   "conv2d_bwd_data_masked")
         return
-    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 1) if USE_DIRECT else 0
-    if n:
+    def igemm():
+        if d.KH * d.KW > 1 and USE_TRANSPOSED_W:
+            wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            nat.check(L.mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
+            nat.check(L.mgvae_conv2d_bwd_data_tw(ctypes.byref(d), _p(y), _p(wt), _p(b), _p(x), _s()), "conv2d_bwd_data_tw")
+        else:
+            nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d), _p(y), _p(w), _p(b), _p(x), _s()), "conv2d_bwd_data")
+
+    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 1) if (USE_DIRECT and _direct_candidate(d)) else 0
+    if not n:
+        return igemm()
+
+    def direct():
         wp = torch.empty((n,), device=w.device, dtype=torch.float32)
         nat.check(L.mgvae_conv_pack(ctypes.byref(d), 1, _p(w), _p(wp), _s()), "conv_pack")
         nat.check(L.mgvae_conv2d_bwd_data_packed(ctypes.byref(d), _p(y), _p(wp), _p(b), _p(x), _s()), "conv2d_bwd_data_packed")
-    elif d.KH * d.KW > 1 and USE_TRANSPOSED_W:
-        wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-        nat.check(L.mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
-        nat.check(L.mgvae_conv2d_bwd_data_tw(ctypes.byref(d), _p(y), _p(wt), _p(b), _p(x), _s()), "conv2d_bwd_data_tw")
+
+    if USE_DIRECT is True or _direct_wins(1, d, igemm, direct):
+        direct()
     else:
-        nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d), _p(y), _p(w), _p(b), _p(x), _s()), "conv2d_bwd_data")
+        igemm()
 
 
 # ---- side streams: independent work of one backward node (the weight gradient vs the data gradient of a conv) and

@@ -40,3 +40,28 @@ for name, N, Cx, H, W, Cy, k, st, p in CASES:
         us = e0.elapsed_time(e1)*1e3/20
         res.append((flops/us/1e6, us))
     print("%-28s %5.1f/%-6.0f %5.1f/%-6.0f %5.1f/%-6.0f" % (name, res[0][0], res[0][1], res[1][0], res[1][1], res[2][0], res[2][1]))
+
+# ---- the direct (halo-tile, packed-weight) kernels on the same cases: forward only, pack time excluded / included
+print("\n%-28s %12s %12s   (direct fwd: TFLOP/s kernel only; with weight packing)" % ("case", "direct", "direct+pack"))
+for name, N, Cx, H, W, Cy, k, st, p in CASES:
+    OH = (H + 2*p - k)//st + 1; OW = (W + 2*p - k)//st + 1
+    x = torch.randn(N, Cx, H, W, device=dev); y = torch.empty(N, Cy, OH, OW, device=dev); w = torch.randn(Cy, Cx, k, k, device=dev)
+    d = nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k, k, st, st, p, p, Cx, 0, Cy, 0, 0, 0.0)
+    n = L.mgvae_conv_pack_floats(ctypes.byref(d), 0)
+    if not n:
+        print("%-28s %12s" % (name, "unsupported")); continue
+    wp = torch.empty(n, device=dev)
+    flops = 2.0*N*OH*OW*Cy*Cx*k*k
+    pack = lambda: L.mgvae_conv_pack(ctypes.byref(d), 0, vp(w), vp(wp), s)
+    run = lambda: L.mgvae_conv2d_fwd_packed(ctypes.byref(d), vp(x), vp(wp), None, vp(y), s)
+    res = []
+    for fn in (run, lambda: (pack(), run())):
+        pack()
+        for _ in range(3): fn()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1)*1e3/20
+        res.append((flops/us/1e6, us))
+    print("%-28s %5.1f/%-6.0f %5.1f/%-6.0f" % (name, res[0][0], res[0][1], res[1][0], res[1][1]))
