@@ -493,13 +493,10 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_wgrad_kernel(const float* __
         a2 += dpre[(size_t)n * C + c] * (hn[j] + hn[Cr + j]);
         a1 += dn[j] * avg[(size_t)n * C + c] + dn[Cr + j] * mx[(size_t)n * C + c];
     }
-    if (gridDim.y == 1) {
-        if (dw2) dw2[(size_t)c * Cr + j] += a2;
-        if (dw1) dw1[(size_t)j * C + c] += a1;
-    } else {
-        if (dw2) atomicAdd(&dw2[(size_t)c * Cr + j], a2);
-        if (dw1) atomicAdd(&dw1[(size_t)j * C + c], a1);
-    }
+    // always atomic: the same CBAM may be running its backward on another stream (two halves of a batch, see
+    // graph/model.py::Model.encode_phrase), and the sample chunks of one launch share the element anyway
+    if (dw2) atomicAdd(&dw2[(size_t)c * Cr + j], a2);
+    if (dw1) atomicAdd(&dw1[(size_t)j * C + c], a1);
 }
 
 // B5: du += davg/P + [p == argmax_hw] dmaxp

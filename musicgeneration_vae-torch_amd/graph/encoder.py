@@ -31,7 +31,8 @@ class _ConvTrunk(nn.Module):
         self.last_kl = None
         self.apply(weights_init)
 
-    def forward(self, x):
+    def features(self, x):
+        """the conv trunk up to the pooled [n, 1024] features (everything but the final Linear)"""
         n, _, h, w = x.shape
         cat = torch.empty((n, 64, h // 2, w // 2), device=x.device, dtype=torch.float32)
         pitch = self.pitch_time(x, out=cat[:, :32])
@@ -41,7 +42,10 @@ class _ConvTrunk(nn.Module):
             o = blk(o)
         if tuple(o.shape[2:]) != self.pool_hw:
             raise RuntimeError("AvgPool2d%s expects a %s map, got %s" % (self.pool_hw, self.pool_hw, tuple(o.shape[2:])))
-        feat = HF.global_avg_pool(o)
+        return HF.global_avg_pool(o)
+
+    def forward(self, x):
+        feat = self.features(x)
         mean = self.linear(feat)
         if not self.variational:
             return mean
