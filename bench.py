@@ -206,6 +206,14 @@ def main():
     log("timed region: %.1f ms/step" % (1e3 * dt / args.steps))
 
     roof = None
+    if not args.no_roofline and rank != 0:
+        # the extra step below contains the gradient all-reduce: every rank has to take part in it
+        import graph.model as gm
+        saved = (HF.FORK_WGRAD, HF.FORK_BRANCHES, gm.OVERLAP_TRUNKS)
+        HF.FORK_WGRAD = HF.FORK_BRANCHES = gm.OVERLAP_TRUNKS = False
+        eager_step(*batch)
+        torch.cuda.synchronize()
+        HF.FORK_WGRAD, HF.FORK_BRANCHES, gm.OVERLAP_TRUNKS = saved
     if not args.no_roofline and rank == 0:
         # one extra (untimed) step with every conv launch bracketed by hipEvents on its stream
         L = nat.lib()
@@ -265,6 +273,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
