@@ -185,12 +185,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log("model built on %s (%d CUs); warm-up" % (arch.value.decode(), cus.value))
+    log("model built on %s (%d CUs); set-up step" % (arch.value.decode(), cus.value))
+    # set-up (not one of the W warm-up steps): the first step uploads the per-geometry gather tables and runs the conv
+    # autotuner's trial launches, like the reference's first cudnn.benchmark iteration; it must not leak into the timed
+    # region even with --warmup 0
+    step(*batch)
+    torch.cuda.synchronize()
+    log("set-up step done; %d warm-up steps" % args.warmup)
     for i in range(args.warmup):
         step(*batch)
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first step done")
     sync_all()
     log("timing %d steps" % args.steps)
     t0 = time.perf_counter()
