@@ -14,7 +14,12 @@
  *     filled on the first call of each conv geometry (run one warm-up step before
  *     capturing a hipGraph);
  *   - every call only enqueues work on `stream` (a hipStream_t passed as void*);
- *     no implicit synchronisation, safe under hipGraph stream capture;
+ *     no implicit synchronisation, safe under hipGraph stream capture.  One exception,
+ *     outside capture only: the FIRST call of a (mode, conv geometry, batch) uploads that
+ *     table synchronously and, unless MGVAE_AUTOTUNE=0, times the candidate (tile, split-K)
+ *     launches with events on `stream` (weight-gradient trials accumulate into a
+ *     hipMalloc'd scratch buffer, never into the caller's gradient); the decision is cached
+ *     for the process (MGVAE_AUTOTUNE_FILE persists it);
  *   - return 0 on success, a negative MGVAE_E* code otherwise (mgvae_strerror());
  *   - "accumulate" outputs (weight / bias / affine gradients, embedding gradient) are
  *     ADDED into the destination, which the caller zeroes once per optimizer step;
