@@ -1132,17 +1132,14 @@ static int pick_tile(long Itot, long Jtot, int Z, long Kmin, int* ksplit, bool a
     const long maxsplit = (allow_split && Kmin / (BK * 8) > 1) ? Kmin / (BK * 8) : 1;
     if (wgs(ti, tj) * maxsplit < want && tj == 2) tj = 1;
     if (wgs(ti, tj) * maxsplit < want && ti == 2) ti = 1;
-    static const int env_tile4 = getenv("MGVAE_TILE4") ? atoi(getenv("MGVAE_TILE4")) : 0;
-    if (env_tile4 && ti == 2 && tj == 2 && Itot >= 256 && wgs(4, 2) * maxsplit >= want) ti = 4;   // 256 x 128
     long sp = cdiv(want, wgs(ti, tj));
     if (sp > maxsplit) sp = maxsplit;
     if (sp > 32) sp = 32;
     *ksplit = sp < 1 ? 1 : (int)sp;
-    if (ti == 4) return 4;
     return (ti == 2 ? 0 : 1) + (tj == 2 ? 0 : 2);
 }
-static inline int tile_it(int tile) { return tile == 4 ? 256 : (tile & 1) ? 64 : 128; }
-static inline int tile_jt(int tile) { return tile == 4 ? 128 : (tile & 2) ? 64 : 128; }
+static inline int tile_it(int tile) { return (tile & 1) ? 64 : 128; }
+static inline int tile_jt(int tile) { return (tile & 2) ? 64 : 128; }
 
 static void zero_slice(float* t, int N, int C, long P, int ctot, hipStream_t s) {
     const long row = (long)C * P, total = row * N;
@@ -1180,7 +1177,6 @@ static int launch(int tile, dim3 grid, const IgemmP& p, hipStream_t s) {
         case 0: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, p); break;
         case 1: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 2>), grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((igemm_kernel<MODE, 2, 1>), grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((igemm_kernel<MODE, 4, 2>), grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL((igemm_kernel<MODE, 1, 1>), grid, dim3(256), 0, s, p); break;
     }
     MGVAE_CHECK_LAUNCH();
