@@ -112,7 +112,7 @@ struct ChanTap {
 
 // ---------------------------------------------------------------------------------------
 template <int MODE, int TI, int TJ>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void igemm_kernel(const IgemmP p) {
     constexpr int IT = 64 * TI, JT = 64 * TJ;
     constexpr bool A_IK = (MODE != MODE_BWD_DATA);   // weights [cy][k] / dY [cy][pix]: k contiguous
     constexpr bool B_KJ = (MODE != MODE_BWD_WEIGHT); // gathers with pixels along lanes
