@@ -197,17 +197,34 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_mini_kernel(
 }
 
 // ------------------------------------------------------------------------ register-resident variants
+// WPP waves per plane: 1 (a wave owns a plane) or 4 (the whole workgroup owns one big plane: a quarter of the
+// registers per lane, so four times the waves in flight -- 184 VGPRs held the P = 5760 planes to 2 waves per SIMD)
+template <int WPP>
+__device__ __forceinline__ float plane_sum(float v, float* sh, int wave, int lane) {
+    v = wave_sum(v);
+    if constexpr (WPP == 1) return v;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    const float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+
 // P % 4 == 0 and P <= 256*NV: the whole plane lives in NV float4 registers per lane, so x (and dy)
 // are read from HBM exactly once, as 16-byte lane-contiguous loads.
-template <int NV>
+template <int NV, int WPP>
 __global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ stats, int NC, int C, int P, int y_ctot, int y_coff,
     float eps, int act, float slope, float* __restrict__ pavg, float* __restrict__ pmax, int* __restrict__ pidx) {
+    __shared__ float sh[4];
+    __shared__ int shi[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int nc = blockIdx.x * 4 + wave;
+    const int nc = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (nc >= NC) return;
+    const int L = WPP == 1 ? lane : (int)threadIdx.x;      // this thread's float4 slot within the plane
+    constexpr int STR = 64 * WPP;
     const int n = nc / C, c = nc - n * C;
     const int P4 = P >> 2;
     const float4* xp = reinterpret_cast<const float4*>(x + (size_t)nc * P);
@@ -215,28 +232,28 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const int i = lane + 64 * k;
+        const int i = L + STR * k;
         v[k] = i < P4 ? xp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
-    const float mean = wave_sum(s) / (float)P;
+    const float mean = plane_sum<WPP>(s, sh, wave, lane) / (float)P;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        if (lane + 64 * k < P4) {
+        if (L + STR * k < P4) {
             const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
             q += (a * a + b * b) + (cc * cc + d * d);
         }
     }
-    const float var = wave_sum(q) / (float)P;
+    const float var = plane_sum<WPP>(q, sh, wave, lane) / (float)P;
     const float rstd = 1.0f / sqrtf(var + eps);
-    if (lane == 0) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
+    if (L == 0) { stats[2 * nc] = mean; stats[2 * nc + 1] = rstd; }
     const float g = gamma[c], b = beta[c];
     float4* yp = reinterpret_cast<float4*>(y + ((size_t)n * y_ctot + y_coff + c) * P);
     float ps = 0.f, pm = -INFINITY; int pi = 0x7fffffff;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const int i = lane + 64 * k;
+        const int i = L + STR * k;
         if (i < P4) {
             float4 o;
             o.x = apply_act((v[k].x - mean) * rstd * g + b, act, slope);
@@ -251,19 +268,45 @@ __global__ __launch_bounds__(256) void instance_norm_fwd_vec_kernel(
             if (o.w > pm) { pm = o.w; pi = 4 * i + 3; }
         }
     }
-    if (pavg) pool_finish(ps, pm, pi, P, lane, pavg + nc, pmax + nc, pidx + nc);
+    if (pavg) {
+        if constexpr (WPP == 1) {
+            pool_finish(ps, pm, pi, P, lane, pavg + nc, pmax + nc, pidx + nc);
+        } else {                                   // wave-level (sum, max, first argmax), then across the four waves
+            ps = wave_sum(ps);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float om = __shfl_xor(pm, o, 64);
+                const int oi = __shfl_xor(pi, o, 64);
+                if (om > pm || (om == pm && oi < pi)) { pm = om; pi = oi; }
+            }
+            __shared__ float shs[4], shm[4];
+            if (lane == 0) { shs[wave] = ps; shm[wave] = pm; shi[wave] = pi; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float ts = 0.f, tm = -INFINITY; int ti = 0x7fffffff;
+                for (int w = 0; w < 4; ++w) {
+                    ts += shs[w];
+                    if (shm[w] > tm || (shm[w] == tm && shi[w] < ti)) { tm = shm[w]; ti = shi[w]; }
+                }
+                pavg[nc] = ts / (float)P; pmax[nc] = tm; pidx[nc] = ti;
+            }
+        }
+    }
 }
 
-template <int NV>
+template <int NV, int WPP>
 __global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats, const float* __restrict__ dy, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int NC, int C, int P, int dy_ctot, int dy_coff,
     int act, float slope, const float* __restrict__ addc, const float* __restrict__ addp, const int* __restrict__ addi) {
+    __shared__ float sh[4];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int nc = blockIdx.x * 4 + wave;
+    const int nc = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (nc >= NC) return;
+    const int L = WPP == 1 ? lane : (int)threadIdx.x;
+    constexpr int STR = 64 * WPP;
     const int n = nc / C, c = nc - n * C;
     const int P4 = P >> 2;
     const float ac = addc ? addc[nc] / (float)P : 0.f, ap = addc ? addp[nc] : 0.f;
@@ -278,7 +321,7 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const int i = lane + 64 * k;
+        const int i = L + STR * k;
         if (i < P4) {
             const float4 xv = xp[i];
             float4 gv = dyp[i];
@@ -297,15 +340,15 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
             xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); gr[k] = xh[k];
         }
     }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) {
+    s1 = plane_sum<WPP>(s1, sh, wave, lane); s2 = plane_sum<WPP>(s2, sh, wave, lane);
+    if (L == 0) {
         if (dgamma) atomicAdd(&dgamma[c], s2);
         if (dbeta) atomicAdd(&dbeta[c], s1);
     }
     const float m1 = s1 / (float)P, m2 = s2 / (float)P, kq = g * rstd;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const int i = lane + 64 * k;
+        const int i = L + STR * k;
         if (i < P4) {
             float4 o;
             o.x = kq * (gr[k].x - m1 - xh[k].x * m2); o.y = kq * (gr[k].y - m1 - xh[k].y * m2);
@@ -318,7 +361,7 @@ __global__ __launch_bounds__(256) void instance_norm_bwd_vec_kernel(
 static inline int pick_nv(int P) {          // float4 slots per lane, or 0 for the generic kernel
     if (P & 3) return 0;
     const int need = (P / 4 + 63) / 64;
-    return need <= 1 ? 1 : need <= 2 ? 2 : need <= 6 ? 6 : need <= 23 ? 23 : 0;
+    return need <= 1 ? 1 : need <= 2 ? 2 : need <= 6 ? 6 : need <= 24 ? 24 : 0;   // 24: one workgroup per plane, 6 slots per lane
 }
 
 // ------------------------------------------------------------------------ row mean
@@ -483,7 +526,7 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
     if (y_coff < 0 || y_coff + C > y_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-#define MGVAE_INF(NV) hipLaunchKernelGGL(instance_norm_fwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
+#define MGVAE_INF(NV) hipLaunchKernelGGL((instance_norm_fwd_vec_kernel<NV, 1>), dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
                                          gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx)
     if (P <= 24) {
         hipLaunchKernelGGL((instance_norm_fwd_mini_kernel<8, 3>), dim3(cdiv((long)NC * 8, 256)), dim3(256), 0, as_stream(stream), x,
@@ -496,7 +539,10 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
         case 1: MGVAE_INF(1); break;
         case 2: MGVAE_INF(2); break;
         case 6: MGVAE_INF(6); break;
-        case 23: MGVAE_INF(23); break;
+        case 24:
+            hipLaunchKernelGGL((instance_norm_fwd_vec_kernel<6, 4>), dim3(NC), dim3(256), 0, as_stream(stream), x, gamma, beta, y, stats,
+                               NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx);
+            break;
         default:
             hipLaunchKernelGGL(instance_norm_fwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
                                beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx);
@@ -515,7 +561,7 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
     if (dy_coff < 0 || dy_coff + C > dy_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
-#define MGVAE_INB(NV) hipLaunchKernelGGL(instance_norm_bwd_vec_kernel<NV>, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
+#define MGVAE_INB(NV) hipLaunchKernelGGL((instance_norm_bwd_vec_kernel<NV, 1>), dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
                                          gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const, \
                                          add_point, add_index)
     if (P <= 24) {
@@ -531,7 +577,10 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
         case 1: MGVAE_INB(1); break;
         case 2: MGVAE_INB(2); break;
         case 6: MGVAE_INB(6); break;
-        case 23: MGVAE_INB(23); break;
+        case 24:
+            hipLaunchKernelGGL((instance_norm_bwd_vec_kernel<6, 4>), dim3(NC), dim3(256), 0, as_stream(stream), x, gamma, beta, stats, dy,
+                               dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const, add_point, add_index);
+            break;
         default:
             hipLaunchKernelGGL(instance_norm_bwd_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, gamma,
                                beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const,
