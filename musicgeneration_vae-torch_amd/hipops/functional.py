@@ -209,6 +209,10 @@ SERIAL = _os.environ.get("MGVAE_SERIAL", "0") != "0"       # one stream only: pe
 FORK_WGRAD = _os.environ.get("MGVAE_FORK_WGRAD", "1") != "0" and not SERIAL
 _side_streams = {}      # (device index, id of the stream forked from) -> side stream
 _used_sides = {}        # streams with work of the running backward pass, to be joined by _join_sides
+# forking costs the host ~30 us per conv backward (events, allocator bookkeeping): it pays when the step is bound by the
+# GPU (batch 64: 30.5 -> 27.4 ms) and costs when the host's launch rate is the bound (the ~2000-launch GAN iteration at
+# 16 bars per GPU: 26.0 -> 29.1 ms), so small batches stay on one stream
+FORK_MIN_BATCH = int(_os.environ.get("MGVAE_FORK_MIN_BATCH", "32"))
 WGRAD_STREAMS = int(_os.environ.get("MGVAE_WGRAD_STREAMS", "1"))   # side streams the weight gradients rotate over
 _wgrad_rr = [0]
 _join_queued = [-1]      # id of the autograd graph task that already has the join callback queued
@@ -364,7 +368,7 @@ class _ConvFn(torch.autograd.Function):
             if b is not None and b.requires_grad:
                 nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Cy, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
 
-        if FORK_WGRAD and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
+        if FORK_WGRAD and N >= FORK_MIN_BATCH and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
             _wgrad_rr[0] += 1
             with _forked(x, dy, slot=2 + _wgrad_rr[0] % WGRAD_STREAMS):   # the weight gradient runs beside the data gradient below
                 weight_grads()
@@ -444,7 +448,7 @@ class _ConvTFn(torch.autograd.Function):
             if b is not None and b.requires_grad:
                 nat.check(L.mgvae_channel_sum_accum(_p(dy), N, Co, OH * OW, dct, 0, _p(grad_slot(b)), _s()), "bias_grad")
 
-        if FORK_WGRAD and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
+        if FORK_WGRAD and N >= FORK_MIN_BATCH and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
             _wgrad_rr[0] += 1
             with _forked(x, dy, slot=2 + _wgrad_rr[0] % WGRAD_STREAMS):
                 weight_grads()
