@@ -28,7 +28,9 @@ def _p(t):
 
 
 def _s():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream as a void* (raw C entry points: torch.cuda.current_stream() costs ~8 us of Python per call,
+    161 calls in a forward pass)"""
+    return _vp(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _need_cuda(t, what):
