@@ -38,6 +38,9 @@ class _ConvTrunk(nn.Module):
         pitch = self.pitch_time(x, out=cat[:, :32])
         time = self.time_pitch(x, out=cat[:, 32:])
         o = HF.join(cat, pitch, time)
+        # when the gradient of this tensor exists, every parameter gradient of ``layers`` and ``linear`` is enqueued:
+        # the data-parallel step hooks it to start that range's all-reduce early (hipops/train.py)
+        self.trunk_input = o if o.requires_grad else None
         for blk in self.layers:
             o = blk(o)
         if tuple(o.shape[2:]) != self.pool_hw:

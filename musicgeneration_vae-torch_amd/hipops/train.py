@@ -32,6 +32,14 @@ class PretrainStep:
         self.dec_range = (self.opt.offsets[min(dec)],
                           self.opt.offsets[max(dec)] + self.opt.params[max(dec)].numel())
         self.dec_range = (self.dec_range[0], (self.dec_range[1] + 63) // 64 * 64)
+        # flat range of the bar encoder's trunk (layers + linear; its two stems finish last and go with the rest)
+        enc = getattr(generator, "encoder", None)
+        self.enc_range = None
+        if enc is not None and hasattr(enc, "layers") and hasattr(enc, "linear"):
+            idx = [ids[id(p)] for m in (enc.layers, enc.linear) for p in m.parameters()]
+            if idx and max(idx) - min(idx) + 1 == len(idx):          # contiguous in the flat buffer
+                self.enc_range = (self.opt.offsets[min(idx)],
+                                  (self.opt.offsets[max(idx)] + self.opt.params[max(idx)].numel() + 63) // 64 * 64)
 
     def _arm_overlap(self, tensors):
         """when the gradients of all decoder INPUTS have been produced, every decoder
@@ -47,6 +55,11 @@ class PretrainStep:
 
         for t in tensors:
             t.register_hook(fire)
+        # second early bucket: the bar-encoder trunk, while the (twice as long) phrase trunk is still in backward
+        enc = getattr(self.gen, "encoder", None)
+        t_in = getattr(enc, "trunk_input", None) if enc is not None else None
+        if self.enc_range is not None and t_in is not None:
+            t_in.register_hook(lambda _g: self.reducer.reduce_range(*self.enc_range))
 
     def forward_loss(self, note, pre_note, phrase, position, is_pretraining=True):
         """generator forward + the four loss terms.  The three frozen z-discriminator passes depend only on the
