@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_kernel(
         if (mode == 2) dres[(size_t)nc * P + i] = g;
     }
     acc = wave_sum(acc);
-    if (lane == 0) dcg[nc] = acc;
+    if (lane == 0) dcg[nc] = acc * g_c * (1.f - g_c);      // = d(pre-sigmoid): the gate MLP backward starts from it
 }
 
 // float4 variant of B3 (P % 4 == 0)
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_vec_kernel(
         if (mode == 2) drp[i] = g;
     }
     acc = wave_sum(acc);
-    if (lane == 0) dcg[nc] = acc;
+    if (lane == 0) dcg[nc] = acc * g_c * (1.f - g_c);      // = d(pre-sigmoid): the gate MLP backward starts from it
 }
 
 // small planes (P <= G*E): G lanes per (n, c) plane, several planes per wave (see norm.hip, small planes)
@@ -417,16 +417,11 @@ __global__ __launch_bounds__(256) void cbam_bwd_channel_mini_kernel(
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-    if (l == 0 && live) dcg[nc] = acc;
+    if (l == 0 && live) dcg[nc] = acc * g_c * (1.f - g_c);
 }
 
-// B4a: MLP backward, fully parallel: (1) dpre[n,c] = dcg * cg * (1 - cg) in place; (2) one wave per
-// (n, j): dh = W2[:,j] . dpre[n,:], masked by the two ReLUs; (3) one thread per (n, c): davg / dmaxp.
-__global__ __launch_bounds__(256) void cbam_bwd_dpre_kernel(float* __restrict__ dcg, const float* __restrict__ cg, int total) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < total) { const float g = cg[i]; dcg[i] = dcg[i] * g * (1.f - g); }
-}
-
+// B4a: MLP backward, fully parallel: dpre[n,c] = dcg * cg * (1 - cg) is already what B3 stored; (1) one wave per
+// (n, j): dh = W2[:,j] . dpre[n,:], masked by the two ReLUs; (2) one thread per (n, c): davg / dmaxp.
 __global__ __launch_bounds__(256) void cbam_bwd_dh_kernel(const float* __restrict__ dpre, const float* __restrict__ hid,
                                                           const float* __restrict__ w2, float* __restrict__ dh, int N, int C) {
     const int Cr = C / 16;
@@ -619,7 +614,6 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
         hipLaunchKernelGGL(cbam_bwd_channel_kernel, dim3(cdiv(NC, 4)), dim3(256), 0, s, u, y, dy, sv.cg, sv.sg, ds_in,
                            sv.amax_c, du, dres, dcg, N, C, P, y_ctot, y_coff, mode, act, slope);
     if (!chan) { MGVAE_CHECK_LAUNCH(); return MGVAE_OK; }   // no channel gate: du is complete
-    hipLaunchKernelGGL(cbam_bwd_dpre_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dcg, sv.cg, NC);
     hipLaunchKernelGGL(cbam_bwd_dh_kernel, dim3(cdiv((long)N * Cr, 4)), dim3(256), 0, s, dcg, sv.hid, w2, dh, N, C);
     hipLaunchKernelGGL(cbam_bwd_dpool_kernel, dim3(cdiv(NC, 256)), dim3(256), 0, s, dh, w1, davg, dmaxp, N, C);
     if (dw1 || dw2) {
