@@ -84,7 +84,7 @@ def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
     return nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], x_ctot, 0, y_ctot, 0, act, slope)
 
 
-USE_TRANSPOSED_W = True   # data-gradient / transposed-conv kernels read a [Cy][KK][Cx] copy of the weight
+USE_TRANSPOSED_W = __import__("os").environ.get("MGVAE_TW", "1") != "0"   # data-gradient / transposed-conv kernels read a [Cy][KK][Cx] copy of the weight
 import os as _os
 # direct (halo-tile, packed-weight, register-prefetched) conv kernels vs the implicit GEMM: MGVAE_DIRECT=0 (default)
 # implicit GEMM only, 1 = direct wherever supported, auto = time both the first time a geometry is seen and keep the
