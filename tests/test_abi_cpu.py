@@ -68,3 +68,24 @@ def test_module_state_dicts_match_reference_manifest(built, golden_dir):
     assert abs(m.encoder.layers[0].conv1.weight.mean().item() + 1) < 0.05
     assert m.decoder.layers[3].deConv1.weight.abs().max().item() < 0.1
     assert torch.equal(m.encoder.layers[0].bn.weight, torch.ones(64))
+
+
+def test_host_helpers_without_a_gpu(built):
+    """pure host logic of the step: stacked-latent detection (one discriminator pass over both bar latents), the
+    gradient-bucket splitter, the act-mask struct layout of include/mgvae.h"""
+    from hipops.train import _stacked
+    from hipops.dist import split_buckets
+    from hipops import _native as nat
+    zz = torch.randn(6, 5)
+    a, b = zz[:3], zz[3:]
+    s = _stacked(a, b)
+    assert s is not None and s.shape == (6, 5) and s.data_ptr() == zz.data_ptr()
+    assert _stacked(b, a) is None and _stacked(torch.randn(3, 5), torch.randn(3, 5)) is None
+    assert _stacked(zz[:2], zz[2:4]) is None                     # halves must tile the base exactly
+    bk = split_buckets(0, 300, 128)                              # from the END backwards, 64-element granularity
+    assert bk == [(172, 300), (44, 172), (0, 44)] and split_buckets(3, 3, 128) == []
+    assert sorted(bk)[0][0] == 0 and all(a[0] == b[1] for a, b in zip(bk, bk[1:]))
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mgvae.h")).read()
+    body = re.search(r"typedef struct MgvaeActMask \{(.*?)\} MgvaeActMask;", hdr, re.S).group(1)
+    names = re.findall(r"(\w+)\s*[;,]", body)
+    assert names == [f[0] for f in nat.ActMask._fields_], (names, nat.ActMask._fields_)
