@@ -16,6 +16,7 @@ from graph.weights_initializer import weights_init
 
 import os
 OVERLAP_TRUNKS = os.environ.get("MGVAE_OVERLAP", "1") != "0" and os.environ.get("MGVAE_SERIAL", "0") == "0"
+PHRASE_PRIORITY = int(os.environ.get("MGVAE_PHRASE_PRIORITY", "-1"))
 SPLIT_PHRASE = os.environ.get("MGVAE_SPLIT_PHRASE", "0") != "0"   # two half-batch streams for the phrase trunk: measured -0.5 % -> off
 
 
@@ -50,7 +51,8 @@ class Model(nn.Module):
         cur = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
             from hipops import functional as HF
-            self._side = torch.cuda.Stream()
+            # the phrase trunk is the longer of the two concurrent chains (the critical path): high priority
+            self._side = torch.cuda.Stream(priority=PHRASE_PRIORITY)
             self._side2 = torch.cuda.Stream()
             HF.register_trunk_stream(self._side)      # joined at the end of every backward pass / before an all-reduce
             HF.register_trunk_stream(self._side2)
