@@ -258,6 +258,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     // so the compiler emits one straight-line block: every load of a K tile is in flight together (a
     // predicated load would be a branch + wait per element).  The per-K gather constants come from
     // the ktab table through scalar loads (the K row is wave-uniform).
+    // The per-K gather constants come from scalar loads; with 16-deep K tiles an SMEM round trip per tile would sit
+    // in front of every tile's global loads, so the entries of tile t+1 are requested while tile t's loads are issued.
+    int2 e_pre[NB];
+    int wo_pre[NA];
+    (void)e_pre; (void)wo_pre;
+    auto prefetch_tables = [&](int k0) {
+        if constexpr (MODE != MODE_BWD_WEIGHT) {
+            const int2* __restrict__ kt = ktab + (k0 + jkr0);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) e_pre[r] = kt[r];           // one scalar load (rows are contiguous)
+        }
+        if constexpr (MODE == MODE_BWD_DATA) {
+            const int* __restrict__ wt = wtab + (k0 + ikr0);
+#pragma unroll
+            for (int r = 0; r < NA; ++r) wo_pre[r] = wt[r];
+        }
+    };
     auto load_tile = [&](int k0) {
         // ------------------------------ A operand ------------------------------
         if constexpr (MODE == MODE_FWD) {
@@ -272,10 +289,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         } else if constexpr (MODE == MODE_BWD_DATA) {
             const int KK = p.KH * p.KW;
             const int ai_off = p.w_transposed ? a_i : a_i * KK;
-            const int* __restrict__ wt = wtab + (k0 + ikr0);
             int wo[NA];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) wo[r] = wt[r];          // one scalar load (rows are contiguous)
+            for (int r = 0; r < NA; ++r) wo[r] = wo_pre[r];
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const bool ok = ai_valid & ((k0 + ikr0 + r) < kend);
@@ -294,10 +310,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         // ------------------------------ B operand ------------------------------
         if constexpr (MODE != MODE_BWD_WEIGHT) {
             const rsrc_t src = (MODE == MODE_FWD) ? rX : rY;
-            const int2* __restrict__ kt = ktab + (k0 + jkr0);
             int2 e[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) e[r] = kt[r];           // one scalar load (rows are contiguous)
+            for (int r = 0; r < NB; ++r) e[r] = e_pre[r];
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const int dh = (int)(short)(e[r].y & 0xffff), dw = e[r].y >> 16;
@@ -351,13 +366,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
 
     const int nt = kend > kbeg ? (kend - kbeg + BKc - 1) / BKc : 0;
     if (nt > 0) {
+        prefetch_tables(kbeg);
         load_tile(kbeg);
+        prefetch_tables(kbeg + BKc);                   // (the tables are padded past their end)
         store_tile(0);
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
             if (t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
             mma_tile<TI, TJ, A_IK, B_KJ, BKc>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, wi, wj, l31, h);
+            // entries of tile t+2: requested after the last LDS fragment read (SMEM and LDS share a counter, and an
+            // outstanding scalar load would turn every fragment wait into a full drain), in flight under the LDS
+            // store, the barrier and the start of the next trip
+            prefetch_tables(kbeg + (t + 2) * BKc);
             if (t + 1 < nt) store_tile(buf ^ 1);
             __syncthreads();
         }
@@ -1072,7 +1093,7 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
         int str = 0;
         const int KK = d->KH * d->KW;
         if (mode == MODE_FWD) {
-            str = d->Cx * KK + 32;
+            str = d->Cx * KK + 96;   // padding: the loaders prefetch the table two K tiles ahead
             host.assign(str, make_int2(0, 0));
             for (int c = 0; c < d->Cx; ++c)
                 for (int t = 0; t < KK; ++t) {
@@ -1089,7 +1110,7 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
                 const int nkw = kw0 < d->KW ? (d->KW - kw0 + d->SW - 1) / d->SW : 0;
                 if (nkh * nkw > maxT) maxT = nkh * nkw;
             }
-            str = d->Cy * maxT + 32;
+            str = d->Cy * maxT + 96;
             host.assign((size_t)Z * str, make_int2(0, 0));
             whost.assign((size_t)Z * str, 0);
             for (int ph = 0; ph < Z; ++ph) {
