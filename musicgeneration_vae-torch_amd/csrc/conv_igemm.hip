@@ -63,6 +63,9 @@ __device__ __forceinline__ float buf_load(rsrc_t r, int elem, bool ok) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? elem * 4 : -1, 0, 0));
 }
 
+#ifndef MGVAE_FRAG_AHEAD
+#define MGVAE_FRAG_AHEAD 1
+#endif
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
 
 // ---------------------------------------------------------------------------------------
@@ -72,8 +75,9 @@ template <int TI, int TJ, bool A_IK, bool B_KJ, int BKc>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
                                          f32x16 (&acc)[TI][TJ], int wi, int wj, int l31, int h) {
     constexpr int IT = 64 * TI, JT = 64 * TJ, LDPc = BKc + 1;
-    // register double buffer: the LDS reads of k-step kk+1 are issued before the MFMAs of k-step kk
-    float a[2][TI], b[2][TJ];
+    // register ring: the LDS reads of k-step kk+AHEAD are issued before the MFMAs of k-step kk
+    constexpr int AHEAD = MGVAE_FRAG_AHEAD, RING = AHEAD + 1, KS = BKc / 2;
+    float a[RING][TI], b[RING][TJ];
     auto fetch = [&](int kk, int s) {
         const int k = 2 * kk + h;
 #pragma unroll
@@ -87,16 +91,17 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
             b[s][tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDPc + k];
         }
     };
-    fetch(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < BKc / 2; ++kk) {
-        if (kk + 1 < BKc / 2) fetch(kk + 1, (kk + 1) & 1);
+    for (int kk = 0; kk < AHEAD && kk < KS; ++kk) fetch(kk, kk % RING);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        if (kk + AHEAD < KS) fetch(kk + AHEAD, (kk + AHEAD) % RING);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TJ; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][ti], b[kk & 1][tj], acc[ti][tj], 0, 0, 0);
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][ti], b[kk % RING][tj], acc[ti][tj], 0, 0, 0);
     }
 }
 
