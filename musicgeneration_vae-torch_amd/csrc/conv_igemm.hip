@@ -63,10 +63,21 @@ __device__ __forceinline__ float buf_load(rsrc_t r, int elem, bool ok) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ok ? elem * 4 : -1, 0, 0));
 }
 
+__device__ __forceinline__ float buf_load_b(rsrc_t r, int byte_off) {     // byte_off >= 2^31 (e.g. -1): reads as 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+#ifndef MGVAE_ABL
+#define MGVAE_ABL 0   // timing-only ablations of the main loop (WRONG results): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no LDS fragment reads
+#endif
 #ifndef MGVAE_FRAG_AHEAD
 #define MGVAE_FRAG_AHEAD 1
 #endif
 enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
+enum { KT_PAD_TAP = 31, KT_MAX_TAPS = 31 };
+__device__ __forceinline__ int kt_dh(int y) { return (int)(signed char)(y & 0xff); }
+__device__ __forceinline__ int kt_dw(int y) { return (int)(signed char)((y >> 8) & 0xff); }
+__device__ __forceinline__ int kt_tap(int y) { return (int)((unsigned)y >> 16); }
 
 // ---------------------------------------------------------------------------------------
 // MFMA over one staged K-tile.  A image: A_IK ? As[i][LDP] : As[k][IT];
@@ -95,13 +106,13 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
     for (int kk = 0; kk < AHEAD && kk < KS; ++kk) fetch(kk, kk % RING);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-        if (kk + AHEAD < KS) fetch(kk + AHEAD, (kk + AHEAD) % RING);
+        if (!(MGVAE_ABL & 8) && kk + AHEAD < KS) fetch(kk + AHEAD, (kk + AHEAD) % RING);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
             for (int tj = 0; tj < TJ; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk % RING][ti], b[kk % RING][tj], acc[ti][tj], 0, 0, 0);
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(MGVAE_ABL & 8) ? 0 : kk % RING][ti], b[(MGVAE_ABL & 8) ? 0 : kk % RING][tj], acc[ti][tj], 0, 0, 0);
     }
 }
 
@@ -255,6 +266,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         }
     }
 
+    // Validity of a gathered element = (this thread's pixel, the K row's tap): one bit per tap, computed once.  A set
+    // bit of `nmask` means "outside the image" (bit KT_PAD_TAP: the padding rows past the end of K; all bits: no pixel).
+    // In the loop an element then costs three vector instructions (bit -> 0 / -1, offset, or) instead of two
+    // compares, four adds and a select plus eight scalar ones.
+    unsigned nmask = 0xffffffffu;
+    if constexpr (MODE != MODE_BWD_WEIGHT) {
+        unsigned m = 1u << KT_PAD_TAP;
+        for (int t = 0; t < T; ++t) {
+            const int y = ktab[t].y;                  // channel 0 lists the taps in order
+            const bool in = ((unsigned)(b_r0 + kt_dh(y)) < (unsigned)b_RH) & ((unsigned)(b_c0 + kt_dw(y)) < (unsigned)b_RW);
+            m |= in ? 0u : (1u << t);
+        }
+        if (bj_valid) nmask = m;
+    }
+    const int b_pix4 = b_pix * 4;
+    // weight rows past the end: an offset that stays out of range whatever (small) K offset is added to it
+    int a_base4[NA];
+    (void)a_base4; (void)b_pix4;
+    if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const int gi = i0 + rr + RP * r;
+            a_base4[r] = gi < Itot ? (gi * Ktot + kl) * 4 : (int)0x80000000;
+        }
+    }
+    const int KKw = p.KH * p.KW;
+    const int a_off_bd = ai_valid ? (p.w_transposed ? a_i : a_i * KKw) : 0x20000000;   // elements; << 2 in the loop
+    (void)a_off_bd;
+
     float ra[NA], rb[NB];
     const rsrc_t rX = make_rsrc(p.X, p.x_bytes), rY = make_rsrc(p.Y, p.y_bytes), rW = make_rsrc(p.Wt, p.w_bytes);
     (void)rX; (void)rY; (void)rW;
@@ -281,34 +321,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         }
     };
     auto load_tile = [&](int k0) {
+        if constexpr ((MGVAE_ABL & 64) != 0) {          // timing only: the same number of loads, trivial addresses
+#pragma unroll
+            for (int r = 0; r < NA; ++r) ra[r] = buf_load(MODE == MODE_BWD_WEIGHT ? rY : rW, (int)threadIdx.x + 256 * r + (k0 & 1023), true);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) rb[r] = buf_load(MODE == MODE_FWD ? rX : (MODE == MODE_BWD_DATA ? rY : rX), (int)threadIdx.x + 256 * r + (k0 & 1023), true);
+            return;
+        }
         // ------------------------------ A operand ------------------------------
         if constexpr (MODE == MODE_FWD) {
-            const int gk = k0 + kl;
-            const bool kok = gk < kend;
+            // K rows past kend multiply B rows that read as 0 (padding taps), so only the row bound is checked
+            const int k04 = k0 * 4;
 #pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                const int gi = i0 + rr + RP * r;
-                const bool ok = kok & (gi < Itot);
-                ra[r] = buf_load(rW, gi * Ktot + gk, ok);
-            }
+            for (int r = 0; r < NA; ++r) ra[r] = buf_load_b(rW, a_base4[r] + k04);
         } else if constexpr (MODE == MODE_BWD_DATA) {
-            const int KK = p.KH * p.KW;
-            const int ai_off = p.w_transposed ? a_i : a_i * KK;
             int wo[NA];
 #pragma unroll
             for (int r = 0; r < NA; ++r) wo[r] = wo_pre[r];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                const bool ok = ai_valid & ((k0 + ikr0 + r) < kend);
-                ra[r] = buf_load(rW, wo[r] + ai_off, ok);
-            }
+            for (int r = 0; r < NA; ++r) ra[r] = buf_load_b(rW, (wo[r] + a_off_bd) << 2);
         } else {
             const bool kok = (k0 + kl) < kend;
             const int base = (w_n * p.y_ctot + p.y_coff) * P + w_p;
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
                 const int gi = i0 + rr + RP * r;
-                const bool ok = kok & (gi < Itot);
+                const bool ok = (MGVAE_ABL & 128) ? true : (kok & (gi < Itot));
                 ra[r] = buf_load(rY, base + gi * P, ok);
             }
         }
@@ -320,10 +358,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
             for (int r = 0; r < NB; ++r) e[r] = e_pre[r];
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const int dh = (int)(short)(e[r].y & 0xffff), dw = e[r].y >> 16;
-                const bool ok = bj_valid & ((k0 + jkr0 + r) < kend) & ((unsigned)(b_r0 + dh) < (unsigned)b_RH) &
-                                ((unsigned)(b_c0 + dw) < (unsigned)b_RW);
-                rb[r] = buf_load(src, b_pix + e[r].x, ok);
+                const int inval = __builtin_amdgcn_sbfe((int)nmask, (unsigned)kt_tap(e[r].y), 1u);   // 0 or -1
+                rb[r] = buf_load_b(src, (b_pix4 + e[r].x * 4) | inval);
             }
         } else {
             const bool kok = (k0 + kl) < kend;
@@ -332,8 +368,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
             const int base = (w_n * p.x_ctot + p.x_coff) * HW + r0 * p.W + c0;
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const bool ok = kok & ((unsigned)(r0 + bj_dh[r]) < (unsigned)p.H) &
-                                ((unsigned)(c0 + bj_dw[r]) < (unsigned)p.W);
+                const bool ok = (MGVAE_ABL & 128) ? true : (kok & ((unsigned)(r0 + bj_dh[r]) < (unsigned)p.H) &
+                                ((unsigned)(c0 + bj_dw[r]) < (unsigned)p.W));
                 rb[r] = buf_load(rX, base + bj_off[r], ok);
             }
             // advance this thread's pixel by one K tile
@@ -378,14 +414,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
-            if (t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
+            if (!(MGVAE_ABL & 1) && t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
             mma_tile<TI, TJ, A_IK, B_KJ, BKc>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, wi, wj, l31, h);
             // entries of tile t+2: requested after the last LDS fragment read (SMEM and LDS share a counter, and an
             // outstanding scalar load would turn every fragment wait into a full drain), in flight under the LDS
             // store, the barrier and the start of the next trip
-            prefetch_tables(kbeg + (t + 2) * BKc);
-            if (t + 1 < nt) store_tile(buf ^ 1);
-            __syncthreads();
+            if (!(MGVAE_ABL & (1 | 64))) prefetch_tables(kbeg + (t + 2) * BKc);
+            if (!(MGVAE_ABL & 2) && (!(MGVAE_ABL & 16) || p.N < 0) && t + 1 < nt) store_tile(buf ^ 1);
+            if (!(MGVAE_ABL & 4)) __syncthreads();
         }
     }
 
@@ -641,7 +677,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
             for (int r = 0; r < NB; ++r) e[r] = kt[r];
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const int dh = (int)(short)(e[r].y & 0xffff), dw = e[r].y >> 16;
+                const int dh = kt_dh(e[r].y), dw = kt_dw(e[r].y);
                 const bool ok = bj_valid & ((k0 + jkr0 + r) < kend) & ((unsigned)(b_r0 + dh) < (unsigned)b_RH) &
                                 ((unsigned)(b_c0 + dw) < (unsigned)b_RW);
                 rb[r] = buf_load(src, b_pix + e[r].x, ok);
@@ -1086,7 +1122,9 @@ struct KtabVal { int2* dev; int* wdev; int stride; };
 static std::map<KtabKey, KtabVal> g_ktab;
 static std::mutex g_ktab_mu;
 
-static inline int2 kt_entry(int off, int dh, int dw) { return make_int2(off, (dh & 0xffff) | (dw << 16)); }
+// entry.y = tap row offset (int8) | tap col offset (int8) << 8 | tap index << 16.  The tap index selects one bit of the
+// loader's per-pixel validity mask (<= 31 taps); KT_PAD_TAP marks the padding rows past the end of K (never valid).
+static inline int2 kt_entry(int off, int dh, int dw, int tap) { return make_int2(off, (dh & 0xff) | ((dw & 0xff) << 8) | (tap << 16)); }
 
 static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0) {
     KtabKey key{{mode + 16 * wtrans, d->Cx, d->H, d->W, d->Cy, d->OH, d->OW, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, 0}};
@@ -1097,13 +1135,14 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
         std::vector<int> whost;
         int str = 0;
         const int KK = d->KH * d->KW;
+        if (KK > KT_MAX_TAPS || d->KH > 127 || d->KW > 127) return MGVAE_EINVAL;   // one validity bit per tap, int8 tap offsets
         if (mode == MODE_FWD) {
             str = d->Cx * KK + 96;   // padding: the loaders prefetch the table two K tiles ahead
-            host.assign(str, make_int2(0, 0));
+            host.assign(str, kt_entry(0, 0, 0, KT_PAD_TAP));
             for (int c = 0; c < d->Cx; ++c)
                 for (int t = 0; t < KK; ++t) {
                     const int kh = t / d->KW, kw = t % d->KW;
-                    host[(size_t)c * KK + t] = kt_entry(c * d->H * d->W + kh * d->W + kw, kh, kw);
+                    host[(size_t)c * KK + t] = kt_entry(c * d->H * d->W + kh * d->W + kw, kh, kw, t);
                 }
         } else {
             const int Z = d->SH * d->SW;
@@ -1116,7 +1155,7 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
                 if (nkh * nkw > maxT) maxT = nkh * nkw;
             }
             str = d->Cy * maxT + 96;
-            host.assign((size_t)Z * str, make_int2(0, 0));
+            host.assign((size_t)Z * str, kt_entry(0, 0, 0, KT_PAD_TAP));
             whost.assign((size_t)Z * str, 0);
             for (int ph = 0; ph < Z; ++ph) {
                 const int rh = ph / d->SW, rw = ph % d->SW;
@@ -1129,7 +1168,7 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
                     for (int t = 0; t < T; ++t) {
                         const int jh = t / nkw, jw = t % nkw;
                         const size_t idx = (size_t)ph * str + (size_t)c * T + t;
-                        host[idx] = kt_entry(c * d->OH * d->OW + (qh - jh) * d->OW + (qw - jw), qh - jh, qw - jw);
+                        host[idx] = kt_entry(c * d->OH * d->OW + (qh - jh) * d->OW + (qw - jw), qh - jh, qw - jw, t);
                         const int tapw = (kh0 + d->SH * jh) * d->KW + kw0 + d->SW * jw;
                         whost[idx] = wtrans ? (c * KK + tapw) * d->Cx : c * d->Cx * KK + tapw;
                     }

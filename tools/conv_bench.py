@@ -41,6 +41,8 @@ for name, N, Cx, H, W, Cy, k, st, p in CASES:
         res.append((flops/us/1e6, us))
     print("%-28s %5.1f/%-6.0f %5.1f/%-6.0f %5.1f/%-6.0f" % (name, res[0][0], res[0][1], res[1][0], res[1][1], res[2][0], res[2][1]))
 
+if os.environ.get("CONV_BENCH_NO_DIRECT"):
+    sys.exit(0)
 # ---- the direct (halo-tile, packed-weight) kernels on the same cases: forward only, pack time excluded / included
 print("\n%-28s %12s %12s   (direct fwd: TFLOP/s kernel only; with weight packing)" % ("case", "direct", "direct+pack"))
 for name, N, Cx, H, W, Cy, k, st, p in CASES:
