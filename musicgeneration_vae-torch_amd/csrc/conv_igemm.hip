@@ -225,8 +225,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
     bool ai_valid = false; int a_i = 0;
     // BWD_WEIGHT state
     int w_n = 0, w_p = 0;                      // running pixel of this thread's k lane
-    int bj_off[NB], bj_dh[NB], bj_dw[NB];      // per-row (cx,kh,kw) constants
-    (void)bj_off; (void)bj_dh; (void)bj_dw;
+    int bj_off[NB], bj_tap[NB];                // per-row (cx,kh,kw) constants: source offset, tap index
+    int a_row4[NA];                            // per-row byte offset into dY (out of range past the last row)
+    int2 w_pe = make_int2(0, -1);              // running pixel's {offset of its window origin in X, invalid-tap bits}
+    (void)bj_off; (void)bj_tap; (void)a_row4; (void)w_pe;
 
     if constexpr (MODE == MODE_FWD) {
         const int j = j0 + jc * 64 + lane;
@@ -249,8 +251,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         a_i = i0 + ic * 64 + lane;
         ai_valid = a_i < Itot;
     } else {
+        // ktab here is the per-PIXEL table of the geometry: entry p = {(oh*SH)*W + ow*SW, one bit per tap that falls
+        // outside the image for that pixel}.  The window origin may lie in the padding (negative offsets are fine:
+        // every tap that is used lies inside).
         const int kp = kbeg + kl;
         w_n = kp / P; w_p = kp - w_n * P;
+        w_pe = ktab[w_p];
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
             const int gj = j0 + rr + RP * r;
@@ -258,11 +264,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
                 const int KK = p.KH * p.KW;
                 const int cx = gj / KK, t = gj - cx * KK;
                 const int kh = t / p.KW, kw = t - kh * p.KW;
-                bj_dh[r] = kh - p.PH; bj_dw[r] = kw - p.PW;
+                bj_tap[r] = t;
                 bj_off[r] = cx * HW + (kh - p.PH) * p.W + (kw - p.PW);
             } else {
-                bj_dh[r] = -(1 << 28); bj_dw[r] = 0; bj_off[r] = 0;   // never in range
+                bj_tap[r] = KT_PAD_TAP; bj_off[r] = 0;                // never in range
             }
+        }
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const int gi = i0 + rr + RP * r;
+            a_row4[r] = gi < Itot ? gi * P * 4 : (int)0x80000000;
         }
     }
 
@@ -341,14 +352,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
 #pragma unroll
             for (int r = 0; r < NA; ++r) ra[r] = buf_load_b(rW, (wo[r] + a_off_bd) << 2);
         } else {
+            // past kend: an offset that is out of range with or without a row offset added (buffers are < 2 GB)
             const bool kok = (k0 + kl) < kend;
-            const int base = (w_n * p.y_ctot + p.y_coff) * P + w_p;
+            const int abase4 = kok ? ((w_n * p.y_ctot + p.y_coff) * P + w_p) * 4 : 0x7ffffffc;
 #pragma unroll
-            for (int r = 0; r < NA; ++r) {
-                const int gi = i0 + rr + RP * r;
-                const bool ok = (MGVAE_ABL & 128) ? true : (kok & (gi < Itot));
-                ra[r] = buf_load(rY, base + gi * P, ok);
-            }
+            for (int r = 0; r < NA; ++r) ra[r] = buf_load_b(rY, abase4 + a_row4[r]);
         }
         // ------------------------------ B operand ------------------------------
         if constexpr (MODE != MODE_BWD_WEIGHT) {
@@ -363,18 +371,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
             }
         } else {
             const bool kok = (k0 + kl) < kend;
-            const int oh = w_p / p.OW, ow = w_p - oh * p.OW;
-            const int r0 = oh * p.SH, c0 = ow * p.SW;
-            const int base = (w_n * p.x_ctot + p.x_coff) * HW + r0 * p.W + c0;
+            const int ninv = kok ? w_pe.y : -1;
+            const int base = (w_n * p.x_ctot + p.x_coff) * HW + w_pe.x;
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const bool ok = (MGVAE_ABL & 128) ? true : (kok & ((unsigned)(r0 + bj_dh[r]) < (unsigned)p.H) &
-                                ((unsigned)(c0 + bj_dw[r]) < (unsigned)p.W));
-                rb[r] = buf_load(rX, base + bj_off[r], ok);
+                const int inval = __builtin_amdgcn_sbfe(ninv, (unsigned)bj_tap[r], 1u);   // 0 or -1
+                rb[r] = buf_load_b(rX, ((base + bj_off[r]) << 2) | inval);
             }
-            // advance this thread's pixel by one K tile
+            // advance this thread's pixel by one K tile; its table entry is back before the next tile's loads
             w_p += BKc;
             while (w_p >= P) { w_p -= P; ++w_n; }
+            w_pe = ktab[w_p];
         }
     };
 
@@ -1136,7 +1143,21 @@ static int get_ktab(const MgvaeConvDesc* d, int mode, IgemmP& p, int wtrans = 0)
         int str = 0;
         const int KK = d->KH * d->KW;
         if (KK > KT_MAX_TAPS || d->KH > 127 || d->KW > 127) return MGVAE_EINVAL;   // one validity bit per tap, int8 tap offsets
-        if (mode == MODE_FWD) {
+        if (mode == MODE_BWD_WEIGHT) {
+            const int P = d->OH * d->OW;
+            str = P + 64;
+            host.assign(str, make_int2(0, -1));
+            for (int oh = 0; oh < d->OH; ++oh)
+                for (int ow = 0; ow < d->OW; ++ow) {
+                    const int r0 = oh * d->SH, c0 = ow * d->SW;
+                    unsigned m = 1u << KT_PAD_TAP;
+                    for (int t = 0; t < KK; ++t) {
+                        const int ih = r0 + t / d->KW - d->PH, iw = c0 + t % d->KW - d->PW;
+                        if (ih < 0 || ih >= d->H || iw < 0 || iw >= d->W) m |= 1u << t;
+                    }
+                    host[(size_t)oh * d->OW + ow] = make_int2(r0 * d->W + c0, (int)m);
+                }
+        } else if (mode == MODE_FWD) {
             str = d->Cx * KK + 96;   // padding: the loaders prefetch the table two K tiles ahead
             host.assign(str, kt_entry(0, 0, 0, KT_PAD_TAP));
             for (int c = 0; c < d->Cx; ++c)
@@ -1745,6 +1766,7 @@ extern "C" int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, c
     }
     IgemmP p = make_params(d);
     p.X = x; p.Y = y; p.out = dw; p.Wt = nullptr; p.bias = nullptr;
+    { const int rc = get_ktab(d, MODE_BWD_WEIGHT, p); if (rc != MGVAE_OK) return rc; }
     hipStream_t s = as_stream(stream);
     const long I = d->Cy, J = (long)d->Cx * d->KH * d->KW, M = (long)d->N * d->OH * d->OW;
     const long max_splits = cdiv(M, BK * 8);

@@ -922,7 +922,9 @@ def test_graphed_train_step_matches_eager():
     # order) may move by up to 2*lr*steps apart: compare in L2 over the whole vector, and through the loss
     assert float((a - b).norm() / a.norm()) < 2e-2, float((a - b).norm() / a.norm())
     assert float((a - b).abs().max()) <= 2 * 1e-3 * 5 + 1e-6
-    assert abs(float(lg) - float(le)) <= 1e-4 * abs(float(le)), (float(lg), float(le))
+    # (1e-3: with weights scaled to ~1e-3 and lr 1e-3, five Adam steps amplify the atomics-order noise of the split-K
+    # weight gradients; observed 1e-5 .. 3e-4 from run to run, depending on the split counts the autotuner picked)
+    assert abs(float(lg) - float(le)) <= 1e-3 * abs(float(le)), (float(lg), float(le))
     # training mode: the two dropout masks change between replays
     graphed_base.gen.train()
     gs2 = GraphedPretrainStep(graphed_base, *batch, warmup=1)
