@@ -84,23 +84,20 @@ __device__ __forceinline__ int kt_tap(int y) { return (int)((unsigned)y >> 16); 
 //                               B image: B_KJ ? Bs[k][JT]  : Bs[j][LDP].
 template <int TI, int TJ, bool A_IK, bool B_KJ, int BKc>
 __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const float* __restrict__ Bs,
-                                         f32x16 (&acc)[TI][TJ], int wi, int wj, int l31, int h) {
+                                         f32x16 (&acc)[TI][TJ], int a_off, int b_off) {
     constexpr int IT = 64 * TI, JT = 64 * TJ, LDPc = BKc + 1;
+    // a_off / b_off: this lane's element offset at (k-step 0, MFMA tile 0), computed once per kernel (mma_offsets);
+    // every fragment read below is then base + compile-time constant = one ds_read with an immediate offset
+    const float* __restrict__ ap = As + a_off;
+    const float* __restrict__ bp = Bs + b_off;
     // register ring: the LDS reads of k-step kk+AHEAD are issued before the MFMAs of k-step kk
     constexpr int AHEAD = MGVAE_FRAG_AHEAD, RING = AHEAD + 1, KS = BKc / 2;
     float a[RING][TI], b[RING][TJ];
     auto fetch = [&](int kk, int s) {
-        const int k = 2 * kk + h;
 #pragma unroll
-        for (int ti = 0; ti < TI; ++ti) {
-            const int i = wi * 32 * TI + ti * 32 + l31;
-            a[s][ti] = A_IK ? As[i * LDPc + k] : As[k * IT + i];
-        }
+        for (int ti = 0; ti < TI; ++ti) a[s][ti] = A_IK ? ap[ti * 32 * LDPc + 2 * kk] : ap[2 * kk * IT + ti * 32];
 #pragma unroll
-        for (int tj = 0; tj < TJ; ++tj) {
-            const int j = wj * 32 * TJ + tj * 32 + l31;
-            b[s][tj] = B_KJ ? Bs[k * JT + j] : Bs[j * LDPc + k];
-        }
+        for (int tj = 0; tj < TJ; ++tj) b[s][tj] = B_KJ ? bp[2 * kk * JT + tj * 32] : bp[tj * 32 * LDPc + 2 * kk];
     };
 #pragma unroll
     for (int kk = 0; kk < AHEAD && kk < KS; ++kk) fetch(kk, kk % RING);
@@ -114,6 +111,14 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ As, const flo
             for (int tj = 0; tj < TJ; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(MGVAE_ABL & 8) ? 0 : kk % RING][ti], b[(MGVAE_ABL & 8) ? 0 : kk % RING][tj], acc[ti][tj], 0, 0, 0);
     }
+}
+// lane offsets of mma_tile: A image A_IK ? As[i][LDP] : As[k][IT]; B image B_KJ ? Bs[k][JT] : Bs[j][LDP];
+// i = wi*32*TI + ti*32 + l31, j = wj*32*TJ + tj*32 + l31, k = 2*kk + h
+template <int TI, int TJ, bool A_IK, bool B_KJ, int BKc>
+__device__ __forceinline__ void mma_offsets(int wi, int wj, int l31, int h, int* a_off, int* b_off) {
+    constexpr int IT = 64 * TI, JT = 64 * TJ, LDPc = BKc + 1;
+    *a_off = A_IK ? (wi * 32 * TI + l31) * LDPc + h : h * IT + wi * 32 * TI + l31;
+    *b_off = B_KJ ? h * JT + wj * 32 * TJ + l31 : (wj * 32 * TJ + l31) * LDPc + h;
 }
 
 // Running decode of a K index that enumerates (channel, tap): advance by `step`.
@@ -412,6 +417,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
+    int mma_a_off, mma_b_off;
+    mma_offsets<TI, TJ, A_IK, B_KJ, BKc>(wi, wj, l31, h, &mma_a_off, &mma_b_off);
     const int nt = kend > kbeg ? (kend - kbeg + BKc - 1) / BKc : 0;
     if (nt > 0) {
         prefetch_tables(kbeg);
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void i
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
             if (!(MGVAE_ABL & 1) && t + 1 < nt) load_tile(kbeg + (t + 1) * BKc);
-            mma_tile<TI, TJ, A_IK, B_KJ, BKc>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, wi, wj, l31, h);
+            mma_tile<TI, TJ, A_IK, B_KJ, BKc>(As0 + buf * A_ELEMS, Bs0 + buf * B_ELEMS, acc, mma_a_off, mma_b_off);
             // entries of tile t+2: requested after the last LDS fragment read (SMEM and LDS share a counter, and an
             // outstanding scalar load would turn every fragment wait into a full drain), in flight under the LDS
             // store, the barrier and the start of the next trip
@@ -595,8 +602,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
     bool bj_valid = false; int b_pix = 0, b_r0 = 0, b_c0 = 0, b_RH = 1, b_RW = 1;
     bool ai_valid = false; int a_i = 0;
     int w_n = 0, w_p = 0;                          // (sample, pixel) of this thread's FIRST k of the pair
-    int bj_off[NB2 > 0 ? NB2 : 1], bj_dh[NB2 > 0 ? NB2 : 1], bj_dw[NB2 > 0 ? NB2 : 1];
-    (void)bj_off; (void)bj_dh; (void)bj_dw;
+    int bj_off[NB2 > 0 ? NB2 : 1], bj_tap[NB2 > 0 ? NB2 : 1];
+    int a_row4[NA2 > 0 ? NA2 : 1];                 // weight gradient: per-row byte offset into dY
+    int2 w_pe0 = make_int2(0, -1), w_pe1 = make_int2(0, -1);   // per-pixel table entries of the two k of the pair
+    (void)bj_off; (void)bj_tap; (void)a_row4; (void)w_pe0; (void)w_pe1;
 
     if constexpr (MODE == MODE_FWD) {
         const int j = j0 + jc * 64 + lane;
@@ -619,8 +628,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         a_i = i0 + ic * 64 + lane;
         ai_valid = a_i < Itot;
     } else {
+        // per-pixel table (see igemm_kernel): {window origin offset, invalid-tap bits}
         const int kp = kbeg + kl2;
         w_n = kp / P; w_p = kp - w_n * P;
+        w_pe0 = ktab[w_p];
+        w_pe1 = ktab[w_p + 1 >= P ? w_p + 1 - P : w_p + 1];
 #pragma unroll
         for (int r = 0; r < NB2; ++r) {
             const int gj = j0 + rr + 16 * r;
@@ -628,13 +640,42 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
                 const int KK = p.KH * p.KW;
                 const int cx = gj / KK, t = gj - cx * KK;
                 const int kh = t / p.KW, kw = t - kh * p.KW;
-                bj_dh[r] = kh - p.PH; bj_dw[r] = kw - p.PW;
+                bj_tap[r] = t;
                 bj_off[r] = cx * HW + (kh - p.PH) * p.W + (kw - p.PW);
             } else {
-                bj_dh[r] = -(1 << 28); bj_dw[r] = 0; bj_off[r] = 0;
+                bj_tap[r] = KT_PAD_TAP; bj_off[r] = 0;
             }
         }
+#pragma unroll
+        for (int r = 0; r < NA2; ++r) {
+            const int gi = i0 + rr + 16 * r;
+            a_row4[r] = gi < Itot ? gi * P * 4 : (int)0x80000000;
+        }
     }
+
+    // one validity bit per tap, as in igemm_kernel
+    unsigned nmask = 0xffffffffu;
+    if constexpr (MODE != MODE_BWD_WEIGHT) {
+        unsigned m = 1u << KT_PAD_TAP;
+        for (int t = 0; t < T; ++t) {
+            const int y = ktab[t].y;
+            const bool in = ((unsigned)(b_r0 + kt_dh(y)) < (unsigned)b_RH) & ((unsigned)(b_c0 + kt_dw(y)) < (unsigned)b_RW);
+            m |= in ? 0u : (1u << t);
+        }
+        if (bj_valid) nmask = m;
+    }
+    const int b_pix4 = b_pix * 4;
+    int a_base4[NA2 > 0 ? NA2 : 1];
+    (void)a_base4; (void)b_pix4;
+    if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+        for (int r = 0; r < NA2; ++r) {
+            const int gi = i0 + rr + 16 * r;
+            a_base4[r] = gi < Itot ? (gi * Ktot + kl2) * 4 : (int)0x80000000;
+        }
+    }
+    const int a_off_bd = ai_valid ? (p.w_transposed ? a_i : a_i * (p.KH * p.KW)) : 0x20000000;
+    (void)a_off_bd;
 
     float ra[NA], rb[NB];
     const rsrc_t rX = make_rsrc(p.X, p.x_bytes), rY = make_rsrc(p.Y, p.y_bytes), rW = make_rsrc(p.Wt, p.w_bytes);
@@ -646,33 +687,27 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
         if constexpr (MODE == MODE_BWD_WEIGHT) { if (p1 >= P) { p1 -= P; ++n1; } }
         // ------------------------------ A operand ------------------------------
         if constexpr (MODE == MODE_FWD) {
+            const int k04 = k0 * 4;
 #pragma unroll
             for (int r = 0; r < NA2; ++r) {
-                const int gi = i0 + rr + 16 * r;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int gk = k0 + kl2 + e;
-                    ra[2 * r + e] = buf_load(rW, gi * Ktot + gk, (gk < kend) & (gi < Itot));
-                }
+                ra[2 * r] = buf_load_b(rW, a_base4[r] + k04);
+                ra[2 * r + 1] = buf_load_b(rW, a_base4[r] + k04 + 4);
             }
         } else if constexpr (MODE == MODE_BWD_DATA) {
-            const int KK = p.KH * p.KW;
-            const int ai_off = p.w_transposed ? a_i : a_i * KK;
             const int* __restrict__ wt = wtab + (k0 + ikr0);
             int wo[NA];
 #pragma unroll
             for (int r = 0; r < NA; ++r) wo[r] = wt[r];
 #pragma unroll
-            for (int r = 0; r < NA; ++r) ra[r] = buf_load(rW, wo[r] + ai_off, ai_valid & ((k0 + ikr0 + r) < kend));
+            for (int r = 0; r < NA; ++r) ra[r] = buf_load_b(rW, (wo[r] + a_off_bd) << 2);
         } else {
-            const int base0 = (w_n * p.y_ctot + p.y_coff) * P + w_p;
-            const int base1 = (n1 * p.y_ctot + p.y_coff) * P + p1;
             const bool k0ok = (k0 + kl2) < kend, k1ok = (k0 + kl2 + 1) < kend;
+            const int abase0 = k0ok ? ((w_n * p.y_ctot + p.y_coff) * P + w_p) * 4 : 0x7ffffffc;
+            const int abase1 = k1ok ? ((n1 * p.y_ctot + p.y_coff) * P + p1) * 4 : 0x7ffffffc;
 #pragma unroll
             for (int r = 0; r < NA2; ++r) {
-                const int gi = i0 + rr + 16 * r;
-                ra[2 * r] = buf_load(rY, base0 + gi * P, k0ok & (gi < Itot));
-                ra[2 * r + 1] = buf_load(rY, base1 + gi * P, k1ok & (gi < Itot));
+                ra[2 * r] = buf_load_b(rY, abase0 + a_row4[r]);
+                ra[2 * r + 1] = buf_load_b(rY, abase1 + a_row4[r]);
             }
         }
         // ------------------------------ B operand ------------------------------
@@ -684,27 +719,23 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmP p) {
             for (int r = 0; r < NB; ++r) e[r] = kt[r];
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
-                const int dh = kt_dh(e[r].y), dw = kt_dw(e[r].y);
-                const bool ok = bj_valid & ((k0 + jkr0 + r) < kend) & ((unsigned)(b_r0 + dh) < (unsigned)b_RH) &
-                                ((unsigned)(b_c0 + dw) < (unsigned)b_RW);
-                rb[r] = buf_load(src, b_pix + e[r].x, ok);
+                const int inval = __builtin_amdgcn_sbfe((int)nmask, (unsigned)kt_tap(e[r].y), 1u);
+                rb[r] = buf_load_b(src, (b_pix4 + e[r].x * 4) | inval);
             }
         } else {
             const bool k0ok = (k0 + kl2) < kend, k1ok = (k0 + kl2 + 1) < kend;
-            const int oh0 = w_p / p.OW, ow0 = w_p - oh0 * p.OW;
-            const int oh1 = p1 / p.OW, ow1 = p1 - oh1 * p.OW;
-            const int r00 = oh0 * p.SH, c00 = ow0 * p.SW, r01 = oh1 * p.SH, c01 = ow1 * p.SW;
-            const int base0 = (w_n * p.x_ctot + p.x_coff) * HW + r00 * p.W + c00;
-            const int base1 = (n1 * p.x_ctot + p.x_coff) * HW + r01 * p.W + c01;
+            const int ninv0 = k0ok ? w_pe0.y : -1, ninv1 = k1ok ? w_pe1.y : -1;
+            const int base0 = (w_n * p.x_ctot + p.x_coff) * HW + w_pe0.x;
+            const int base1 = (n1 * p.x_ctot + p.x_coff) * HW + w_pe1.x;
 #pragma unroll
             for (int r = 0; r < NB2; ++r) {
-                const bool ok0 = k0ok & ((unsigned)(r00 + bj_dh[r]) < (unsigned)p.H) & ((unsigned)(c00 + bj_dw[r]) < (unsigned)p.W);
-                const bool ok1 = k1ok & ((unsigned)(r01 + bj_dh[r]) < (unsigned)p.H) & ((unsigned)(c01 + bj_dw[r]) < (unsigned)p.W);
-                rb[2 * r] = buf_load(rX, base0 + bj_off[r], ok0);
-                rb[2 * r + 1] = buf_load(rX, base1 + bj_off[r], ok1);
+                rb[2 * r] = buf_load_b(rX, ((base0 + bj_off[r]) << 2) | __builtin_amdgcn_sbfe(ninv0, (unsigned)bj_tap[r], 1u));
+                rb[2 * r + 1] = buf_load_b(rX, ((base1 + bj_off[r]) << 2) | __builtin_amdgcn_sbfe(ninv1, (unsigned)bj_tap[r], 1u));
             }
             w_p += BKc;
             while (w_p >= P) { w_p -= P; ++w_n; }
+            w_pe0 = ktab[w_p];
+            w_pe1 = ktab[w_p + 1 >= P ? w_p + 1 - P : w_p + 1];
         }
     };
 
