@@ -79,12 +79,6 @@ int mgvae_conv2d_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w
 /* Same result from w_t = mgvae_weight_transpose(w) ([Cy][KH*KW][Cx]): the weight operand then
  * loads contiguously along the lanes.  The transpose is one small HBM pass per call.            */
 int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx, int KK, void* stream);
-/* The same for every conv weight of a flat parameter buffer in one launch (hipops.flat.FlatParams runs it after each
- * optimizer step, so the per-layer transposes leave the backward pass).  items_dev: device array of n_items x 6 int32
- * {first workgroup of the item, float offset of the weight in flat (and of its copy in flat_t), Cy, Cx, KH*KW, 0}, sorted
- * by first workgroup; an item takes ceil(Cx/64)*Cy workgroups; total_blocks = their sum; max_kk = largest KH*KW (<= 64). */
-int mgvae_weight_transpose_batched(const float* flat, float* flat_t, const int32_t* items_dev, int n_items,
-                                   int total_blocks, int max_kk, void* stream);
 int mgvae_conv2d_bwd_data_tw(const MgvaeConvDesc* d, const float* y, const float* w_t, const float* bias,
                              float* x, void* stream);
 /* dWt += corr(X, Y): weight gradient of either layer type (split-K, fp32 atomics)    */

@@ -85,7 +85,6 @@ class Net:
         self.module = module
         self.opt = FlatParams(list(module.parameters()), lr=lr)
         hdist.broadcast_flat(self.opt.flat)
-        self.opt.refresh_transposed()          # the broadcast rewrote the weights
         self.reducer = GradReducer(self.opt.grad, int(bucket_mb) * 1024 * 1024 // 4)
         self.scheduler = ReduceLROnPlateau(self.opt, mode="min", factor=0.8, cooldown=6) if plateau else None
 

@@ -1682,42 +1682,6 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const float* __re
     }
 }
 
-// All conv weights of a flat parameter buffer in ONE launch (after the optimizer step, instead of one small launch in
-// front of every data gradient).  items: n x {first workgroup, float offset in flat / flat_t, Cy, Cx, KK, 0}, sorted.
-__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const float* __restrict__ flat, float* __restrict__ flat_t,
-                                                                       const int* __restrict__ items, int n_items) {
-    extern __shared__ float tile[];
-    int lo = 0, hi = n_items - 1;                       // last item whose first workgroup is <= this one
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (items[mid * 6] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const int* it = items + lo * 6;
-    const int local = (int)blockIdx.x - it[0], Cy = it[2], Cx = it[3], KK = it[4];
-    const int nx = (Cx + 63) / 64;
-    const int cy = local / nx, cx0 = (local - cy * nx) * 64;
-    if (cy >= Cy) return;
-    const float* w = flat + it[1];
-    float* wt = flat_t + it[1];
-    const int n = min(64, Cx - cx0);
-    const float* src = w + ((size_t)cy * Cx + cx0) * KK;
-    for (int e = threadIdx.x; e < n * KK; e += 256) tile[e] = src[e];
-    __syncthreads();
-    for (int e = threadIdx.x; e < n * KK; e += 256) {
-        const int kk = e / n, c = e - kk * n;
-        wt[((size_t)cy * KK + kk) * Cx + cx0 + c] = tile[c * KK + kk];
-    }
-}
-
-extern "C" int mgvae_weight_transpose_batched(const float* flat, float* flat_t, const int* items_dev, int n_items,
-                                              int total_blocks, int max_kk, void* stream) {
-    if (!flat || !flat_t || !items_dev || n_items <= 0 || total_blocks <= 0 || max_kk <= 0 || max_kk > 64) return MGVAE_EINVAL;
-    hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3(total_blocks), dim3(256), 64 * max_kk * sizeof(float),
-                       as_stream(stream), flat, flat_t, items_dev, n_items);
-    MGVAE_CHECK_LAUNCH();
-    return MGVAE_OK;
-}
-
 extern "C" int mgvae_weight_transpose(const float* w, float* w_t, int Cy, int Cx, int KK, void* stream) {
     if (!w || !w_t || Cy <= 0 || Cx <= 0 || KK <= 0 || KK > 64) return MGVAE_EINVAL;
     hipLaunchKernelGGL(weight_transpose_kernel, dim3(cdiv(Cx, 64), Cy), dim3(256), 64 * KK * sizeof(float), as_stream(stream),

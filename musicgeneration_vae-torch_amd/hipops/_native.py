@@ -39,7 +39,6 @@ SIGNATURES = {
     "mgvae_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_conv2d_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_weight_transpose": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "mgvae_weight_transpose_batched": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "mgvae_conv2d_bwd_data_tw": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
     "mgvae_unpack_bits": (c_int, [P, P, ctypes.c_size_t, P]),
     "mgvae_set_compute_dtype": (c_int, [c_int]),

@@ -20,33 +20,6 @@ from . import _native as nat
 
 _ALIGN = 64  # floats
 
-# ---- transposed conv-weight copies -----------------------------------------------------------------------------------
-# The data-gradient kernels read a [Cy][KH*KW][Cx] copy of each conv weight (mgvae_weight_transpose).  Made per call that
-# is one small launch in front of every data gradient (38 per step of the bar VAE); FlatParams instead keeps a second
-# flat buffer with every copy and refreshes all of them in ONE launch right after the optimizer step.  A copy is handed
-# out only while it is provably current: the version counters of the flat buffer and of the parameter must be the ones
-# recorded at the refresh (any torch-side in-place write -- load_state_dict, broadcast, manual init -- bumps them and the
-# caller falls back to transposing on the spot until the next refresh).
-import os as _os
-import weakref as _weakref
-
-TW_BATCH = _os.environ.get("MGVAE_TW_BATCH", "1") != "0"
-_tw_registry = {}      # data_ptr of a conv weight -> (weakref to its FlatParams, index into its _tw_params)
-
-
-def lookup_transposed(w):
-    """the current [Cy][KH*KW][Cx] copy of conv weight ``w`` kept by its FlatParams, or None"""
-    ent = _tw_registry.get(w.data_ptr())
-    if ent is None:
-        return None
-    fp = ent[0]()
-    if fp is None or fp._tw_flat_version != fp.flat._version:
-        return None
-    p, view, ver = fp._tw_params[ent[1]]
-    if p._version != ver or w.numel() != view.numel():
-        return None
-    return view
-
 
 class FlatParams:
     def __init__(self, params, lr=0.002, betas=(0.9, 0.999), eps=1e-8):
@@ -78,45 +51,6 @@ class FlatParams:
         self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
         self._hyper = torch.zeros(4, device=dev, dtype=torch.float32)
         self.param_groups = [{"lr": lr, "params": self.params}]   # ReduceLROnPlateau-compatible surface
-        self._tw_owner = self
-        self._init_transposed()
-
-    # ---- transposed conv-weight copies (see the note at the top of the file) -----------
-    def _init_transposed(self):
-        self._tw_params, self._tw_flat_version, self.flat_t = [], -1, None
-        if not TW_BATCH:
-            return
-        items, blk, maxkk = [], 0, 1
-        for p, o in zip(self.params, self.offsets):
-            if p.dim() == 4 and 1 < p.shape[2] * p.shape[3] <= 64:
-                cy, cx, kk = int(p.shape[0]), int(p.shape[1]), int(p.shape[2] * p.shape[3])
-                items.append((blk, o, cy, cx, kk, 0))
-                blk += (cx + 63) // 64 * cy
-                maxkk = max(maxkk, kk)
-        if not items:
-            return
-        self.flat_t = torch.zeros_like(self.flat)
-        self._tw_items = torch.tensor(items, dtype=torch.int32, device=self.flat.device).contiguous()
-        self._tw_blocks, self._tw_maxkk = blk, maxkk
-        byoff = {o: p for p, o in zip(self.params, self.offsets)}
-        for i, it in enumerate(items):
-            p = byoff[it[1]]
-            self._tw_params.append([p, self.flat_t[it[1]:it[1] + p.numel()], -1])
-            _tw_registry[p.data_ptr()] = (_weakref.ref(self), i)
-        self.refresh_transposed()
-
-    def refresh_transposed(self):
-        """re-make every transposed copy from the current weights (one launch) and mark them current"""
-        fp = self._tw_owner
-        if fp.flat_t is None:
-            return
-        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        vp = lambda t: ctypes.c_void_p(t.data_ptr())
-        nat.check(nat.lib().mgvae_weight_transpose_batched(vp(fp.flat), vp(fp.flat_t), vp(fp._tw_items), len(fp._tw_params),
-                                                           fp._tw_blocks, fp._tw_maxkk, s), "weight_transpose_batched")
-        fp._tw_flat_version = fp.flat._version
-        for ent in fp._tw_params:
-            ent[2] = ent[0]._version
 
     # ---- torch.optim.Optimizer-like surface used by the agents -------------------------
     def zero_grad(self):
@@ -138,7 +72,6 @@ class FlatParams:
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         nat.check(nat.lib().mgvae_adam_step(vp(self.flat), vp(self.grad), vp(self.exp_avg), vp(self.exp_avg_sq),
                                             self.numel, vp(self._hyper), self.eps, grad_scale, s), "adam_step")
-        self.refresh_transposed()
 
     def state_dict(self):
         """torch.optim.Adam's state_dict layout (per-parameter step / exp_avg / exp_avg_sq), so the
@@ -183,8 +116,6 @@ class FlatParams:
         o._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
         o._hyper = torch.zeros(4, device=self.flat.device, dtype=torch.float32)
         o.param_groups = [{"lr": o.lr, "params": o.params}]
-        o._tw_owner = self._tw_owner          # the transposed copies belong to the parameters, not to the moments
-        o._tw_params, o._tw_flat_version, o.flat_t = [], -1, None
         return o
 
     def buckets(self, nbuckets):

@@ -169,17 +169,6 @@ def _conv_fwd(d, x, w, b, y, mask=None):
         igemm()
 
 
-def _transposed(w, d):
-    """the [Cy][KH*KW][Cx] copy of a conv weight: the one its FlatParams keeps current (hipops.flat), else made here"""
-    from . import flat as _flat
-    wt = _flat.lookup_transposed(w)
-    if wt is not None:
-        return wt
-    wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-    nat.check(nat.lib().mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
-    return wt
-
-
 def _conv_bwd_data(d, y, w, b, x, mask=None):
     """X = conv_transpose(Y, Wt) (+bias): direct per-phase kernels when supported; ``mask`` as in _conv_fwd (over X)"""
     L = nat.lib()
@@ -187,13 +176,16 @@ def _conv_bwd_data(d, y, w, b, x, mask=None):
         m, keep = _mask(*mask)
         tw = d.KH * d.KW > 1 and USE_TRANSPOSED_W
         if tw:
-            w = _transposed(w, d)
+            wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            nat.check(L.mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
+            w = wt
         nat.check(L.mgvae_conv2d_bwd_data_masked(ctypes.byref(d), _p(y), _p(w), 1 if tw else 0, _p(b), _p(x), ctypes.byref(m), _s()),
                   "conv2d_bwd_data_masked")
         return
     def igemm():
         if d.KH * d.KW > 1 and USE_TRANSPOSED_W:
-            wt = _transposed(w, d)
+            wt = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+            nat.check(L.mgvae_weight_transpose(_p(w), _p(wt), d.Cy, d.Cx, d.KH * d.KW, _s()), "weight_transpose")
             nat.check(L.mgvae_conv2d_bwd_data_tw(ctypes.byref(d), _p(y), _p(wt), _p(b), _p(x), _s()), "conv2d_bwd_data_tw")
         else:
             nat.check(L.mgvae_conv2d_bwd_data(ctypes.byref(d), _p(y), _p(w), _p(b), _p(x), _s()), "conv2d_bwd_data")

@@ -25,7 +25,6 @@ class PretrainStep:
         self.loss_gen, self.loss_d = loss_gen, loss_d
         self.opt = FlatParams(list(generator.parameters()), lr=lr)
         hdist.broadcast_flat(self.opt.flat)
-        self.opt.refresh_transposed()          # the broadcast rewrote the weights
         self.reducer = GradReducer(self.opt.grad, bucket_elems)
         # flat range of the decoder (the bulk of the gradient, finished first in backward)
         ids = {id(p): i for i, p in enumerate(self.opt.params)}
@@ -175,7 +174,6 @@ class GraphedPretrainStep:
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         nat.check(nat.lib().mgvae_adam_step(vp(opt.flat), vp(opt.grad), vp(opt.exp_avg), vp(opt.exp_avg_sq), opt.numel,
                                             vp(opt._hyper), opt.eps, 1.0, s), "adam_step")
-        opt.refresh_transposed()               # part of the captured program, like in FlatParams.step
         return loss.detach(), gen.detach()
 
     def _eager(self):

@@ -401,46 +401,6 @@ def test_losses():
     assert kl0.item() == 0.0 and torch.equal(z0.cpu(), eps[:4])
 
 
-def test_flat_params_keep_transposed_conv_weights_current():
-    """FlatParams keeps the [Cy][KH*KW][Cx] copy of every conv weight in a second flat buffer, refreshed in one launch
-    after each optimizer step (hipops.flat); a copy is only handed out while it is current: a torch-side in-place write
-    to a weight makes the lookup miss (the conv then transposes on the spot) until the next refresh."""
-    import __graft_entry__ as ge
-    ge.build()
-    from hipops.flat import FlatParams, lookup_transposed
-    torch.manual_seed(3)
-    ws = [torch.nn.Parameter(torch.randn(24, 16, 3, 3, device=dev)), torch.nn.Parameter(torch.randn(70, 130, 4, 4, device=dev)),
-          torch.nn.Parameter(torch.randn(8, 5, 1, 4, device=dev)), torch.nn.Parameter(torch.randn(32, 16, 1, 1, device=dev)),
-          torch.nn.Parameter(torch.randn(40, device=dev))]
-    opt = FlatParams(ws, lr=0.01)
-    want = lambda p: p.detach().reshape(p.shape[0], p.shape[1], -1).permute(0, 2, 1).reshape(-1)
-    for p in ws[:3]:
-        got = lookup_transposed(p)
-        assert got is not None and torch.equal(got, want(p))
-    assert lookup_transposed(ws[3]) is None and lookup_transposed(ws[4]) is None      # 1x1 kernels / vectors have no copy
-    for p in ws:
-        p.grad.copy_(torch.randn_like(p))
-    before = ws[1].detach().clone()
-    opt.step()
-    assert not torch.equal(before, ws[1].detach())
-    for p in ws[:3]:
-        got = lookup_transposed(p)
-        assert got is not None and torch.equal(got, want(p))                          # refreshed with the step
-    with torch.no_grad():
-        ws[0].mul_(2.0)                                                               # a write FlatParams did not make
-    assert lookup_transposed(ws[0]) is None
-    assert lookup_transposed(ws[1]) is not None                                       # the others are still current
-    # the conv op falls back to transposing on the spot: results stay right
-    x = torch.randn(2, 16, 9, 7, device=dev, requires_grad=True)
-    y = HF().conv2d(x, ws[0], None, (1, 1), (1, 1))
-    y.sum().backward()
-    xr = x.detach().double().requires_grad_(True)
-    F.conv2d(xr, ws[0].detach().double(), None, 1, 1).sum().backward()
-    check("conv dx with a stale transposed copy", x.grad, xr.grad)
-    opt.refresh_transposed()
-    assert torch.equal(lookup_transposed(ws[0]), want(ws[0]))
-
-
 def test_flat_adam_matches_torch():
     from hipops import FlatParams
     ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in ((33, 7), (1000,), (5, 5, 3, 3), (1,))]
