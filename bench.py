@@ -199,8 +199,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step(*batch)
+    t_host = time.perf_counter() - t0       # the host's share: time to ENQUEUE the steps (it runs ahead of the GPU)
     sync_all()
     dt = time.perf_counter() - t0
+    log("host enqueue time: %.1f ms/step" % (1e3 * t_host / args.steps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
