@@ -70,8 +70,9 @@ def log(msg):
 T0 = time.perf_counter()
 
 
-def cpu_baseline(batch=4, steps=2):
-    """the oracle's training step (torch CPU fp32, autograd + Adam) on this host's cores"""
+def cpu_baseline(batch=4, min_seconds=12.0, max_steps=60):
+    """the oracle's training step (torch CPU fp32, autograd + Adam) on this host's cores: a bounded sample of about
+    ``min_seconds`` of CPU work after one warm-up step"""
     from oracle import restate as R
     from oracle import weights as W
     torch.set_num_threads(host_cores())
@@ -83,7 +84,8 @@ def cpu_baseline(batch=4, steps=2):
     v = [torch.zeros_like(p) for p in params]
     note, pre, phrase, pos = W.make_inputs(batch, seed=1234)
     times = []
-    for it in range(steps + 1):
+    it = 0
+    while it == 0 or (sum(times) < min_seconds and len(times) < max_steps) or len(times) < 3:
         t0 = time.perf_counter()
         loss, _ = R.pretrain_step_loss(gsd, zsd, zsd, note, pre, phrase, pos, True)
         grads = torch.autograd.grad(loss, params, allow_unused=True)
@@ -91,10 +93,11 @@ def cpu_baseline(batch=4, steps=2):
         R.adam_step(params, grads, m, v, it + 1)
         if it > 0:
             times.append(time.perf_counter() - t0)
+        it += 1
     dt = float(np.median(times))
     return {"value": batch / dt, "unit": "bars/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d timed steps (after 1 warm-up) of the same pre-training step at batch %d, fp32, torch %s CPU"
-                      % (steps, batch, torch.__version__)}
+            "sample": "%d timed steps = %.1f s of CPU work (after 1 warm-up) of the same pre-training step at batch %d, fp32, "
+                      "torch %s CPU; median step" % (len(times), sum(times), batch, torch.__version__)}
 
 
 def pmc_record(kernel):
