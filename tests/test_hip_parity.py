@@ -573,6 +573,63 @@ def test_train_step_against_oracle_and_golden(golden_dir):
         check("adam " + n, params[n].detach().double().cpu() - p0, want - p0, 1e-4)
 
 
+def test_full_size_step_parity_and_batch_properties():
+    """BASELINE.json configs[1] at its full size (64 bars per GPU), three ways:
+      * against the oracle's fp32 step on the host (loss, gradient norms, gradients with the mask-flip rule);
+      * per-sample independence (InstanceNorm + per-sample CBAM, dropout off): the first 4 rows of the 64-bar forward
+        equal the 4-bar forward of those rows -- other tiles, split-K factors and kernel variants are chosen at 4;
+      * linearity: every loss term is a batch mean, so the 64-bar gradient is the mean of the 16 4-bar gradients."""
+    from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
+    from graph.loss.bar_loss import Loss, DLoss
+    from hipops import FlatParams
+    mode, B = "wc", 64
+    m, gsd = _generator(mode)
+    zsd = W.make_state_dict(W.manifest_z_discriminator(), 0, mode)
+    zb, zp = BarZDiscriminator(), PhraseZDiscriminator()
+    zb.load_state_dict(zsd); zp.load_state_dict(zsd)
+    zb, zp = zb.to(dev), zp.to(dev)
+    for d in (zb, zp):
+        for prm in d.parameters():
+            prm.requires_grad = False
+    note, pre, phrase, pos = W.make_inputs(B, seed=4321)
+    opt = FlatParams(list(m.parameters()), lr=0.002)
+    lossf = Loss().to(dev)
+
+    def step(sl):
+        opt.zero_grad()
+        n_, p_, ph_, po_ = (t[sl].to(dev) for t in (note, pre, phrase, pos))
+        gen, z, pz, pf = m(n_, p_, ph_, po_)
+        loss = DLoss.constant(zp(pf).view(-1), 1.0) + DLoss.constant(zb(z).view(-1), 1.0) + DLoss.constant(zb(pz).view(-1), 1.0)
+        loss = loss + lossf(gen, n_, True)
+        loss.backward()
+        return loss.detach(), gen.detach(), opt.grad.clone()
+
+    loss64, gen64, g64 = step(slice(0, B))
+    # (1) the oracle, fp32, same 64 bars
+    osd = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    lo, _ = R.pretrain_step_loss(osd, zsd, zsd, note, pre, phrase, pos, True)
+    params = dict(m.named_parameters())
+    names = [n for n in params if n in osd]
+    og = torch.autograd.grad(lo, [osd[n] for n in names], allow_unused=True)
+    check("full-size step loss vs oracle fp32", loss64, lo.detach(), 1e-4)
+    gscale = max(g.abs().max().item() for g in og if g is not None)
+    for n, g in zip(names, og):
+        if g is None or g.abs().max().item() <= 1e-6 * gscale:
+            continue
+        check_grad("full-size d" + n, params[n].grad, g, 2 * TOL, atol=1e-6 * gscale, l2_ok=3e-2)
+    # (2) per-sample independence
+    _, gen4, _ = step(slice(0, 4))
+    check("rows 0-3 of the 64-bar forward == the 4-bar forward", gen64[:4], gen4, 1e-4)
+    # (3) linearity over the batch
+    acc = torch.zeros_like(g64)
+    for c in range(B // 4):
+        acc += step(slice(4 * c, 4 * c + 4))[2]
+    acc /= B // 4
+    err = float((acc - g64).norm() / g64.norm())
+    REPORT.append("full size: |mean of 16 4-bar gradients - 64-bar gradient| / |64-bar gradient| = %.3e" % err)
+    assert err < 2e-3, err
+
+
 # ------------------------------------------------------------------------- discriminators
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("act", [0, 1])
