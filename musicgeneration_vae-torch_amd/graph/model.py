@@ -52,7 +52,7 @@ class Model(nn.Module):
         if getattr(self, "_side", None) is None:
             from hipops import functional as HF
             # the phrase trunk is the longer of the two concurrent chains (the critical path): high priority
-            self._side = torch.cuda.Stream(priority=PHRASE_PRIORITY)
+            self._side = torch.cuda.Stream(priority=getattr(self, "phrase_stream_priority", PHRASE_PRIORITY))
             self._side2 = torch.cuda.Stream()
             HF.register_trunk_stream(self._side)      # joined at the end of every backward pass / before an all-reduce
             HF.register_trunk_stream(self._side2)

@@ -29,6 +29,10 @@ class Model(nn.Module):
 
     # phrase trunk on a side stream beside the bar trunk (graph/model.py::Model.encode_phrase)
     encode_phrase = _plain.Model.encode_phrase
+    # ... at NORMAL priority here: beside the side-stream weight gradients of the three extra networks of a GAN iteration a
+    # high-priority phrase stream costs 48 -> 80 ms per iteration at 64 bars (tools/bench_gan.py), while the plain
+    # pre-training step gains 1.3 % from it
+    phrase_stream_priority = 0
     join_phrase = _plain.Model.join_phrase
 
     def forward(self, note, pre_note, phrase, position, is_note=True):
