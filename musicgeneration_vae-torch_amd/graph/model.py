@@ -52,7 +52,12 @@ class Model(nn.Module):
         if getattr(self, "_side", None) is None:
             from hipops import functional as HF
             # the phrase trunk is the longer of the two concurrent chains (the critical path): high priority
-            self._side = torch.cuda.Stream(priority=getattr(self, "phrase_stream_priority", PHRASE_PRIORITY))
+            prio = getattr(self, "phrase_stream_priority", PHRASE_PRIORITY)
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # not measured beside RCCL's all-reduce kernels (no multi-GPU box in development), and the one workload
+                # where the priority stream met more concurrent streams lost 65 % (graph/model_with_gan.py): stay neutral
+                prio = 0
+            self._side = torch.cuda.Stream(priority=prio)
             self._side2 = torch.cuda.Stream()
             HF.register_trunk_stream(self._side)      # joined at the end of every backward pass / before an all-reduce
             HF.register_trunk_stream(self._side2)
