@@ -19,6 +19,7 @@ import torch
 from . import _native as nat
 
 _ALIGN = 64  # floats
+_HYPER_RING = 257   # pinned rows for the per-step scalars (row 0 + 256 steps of host run-ahead)
 
 
 class FlatParams:
@@ -48,7 +49,10 @@ class FlatParams:
                 p.grad = g
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        # step-dependent scalars travel through a RING of pinned rows: the host runs several steps ahead of the GPU, and
+        # an async copy of step n must not find the scalars of step n+1 in its source
+        self._hyper_ring = torch.zeros(_HYPER_RING, 4, dtype=torch.float32).pin_memory()
+        self._hyper_host = self._hyper_ring[0]      # the row a captured graph re-reads (GraphedPretrainStep)
         self._hyper = torch.zeros(4, device=dev, dtype=torch.float32)
         self.param_groups = [{"lr": lr, "params": self.params}]   # ReduceLROnPlateau-compatible surface
 
@@ -59,19 +63,30 @@ class FlatParams:
             if p.grad is None:
                 p.grad = p._mg_grad
 
-    def step(self, grad_scale=1.0):
+    def begin_step(self):
+        """count the step and upload its scalars (lr / bias corrections) on the current stream"""
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
-        h = self._hyper_host
+        h = self._hyper_ring[1 + self.step_count % (_HYPER_RING - 1)]      # row 0 belongs to the captured graph
         h[0], h[1], h[2], h[3] = lr / bc1, math.sqrt(bc2), b1, b2
         self._hyper.copy_(h, non_blocking=True)
+
+    def step_range(self, start, end, grad_scale=1.0):
+        """Adam over the flat slice [start, end) on the current stream (after begin_step on a stream it is ordered behind)"""
+        if end <= start:
+            return
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        vp = lambda t: ctypes.c_void_p(t.data_ptr())
-        nat.check(nat.lib().mgvae_adam_step(vp(self.flat), vp(self.grad), vp(self.exp_avg), vp(self.exp_avg_sq),
-                                            self.numel, vp(self._hyper), self.eps, grad_scale, s), "adam_step")
+        vp = lambda t, o: ctypes.c_void_p(t.data_ptr() + 4 * o)
+        nat.check(nat.lib().mgvae_adam_step(vp(self.flat, start), vp(self.grad, start), vp(self.exp_avg, start),
+                                            vp(self.exp_avg_sq, start), end - start, ctypes.c_void_p(self._hyper.data_ptr()),
+                                            self.eps, grad_scale, s), "adam_step")
+
+    def step(self, grad_scale=1.0):
+        self.begin_step()
+        self.step_range(0, self.numel, grad_scale)
 
     def state_dict(self):
         """torch.optim.Adam's state_dict layout (per-parameter step / exp_avg / exp_avg_sq), so the
@@ -113,7 +128,8 @@ class FlatParams:
         o.exp_avg, o.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         o.lr, o.betas, o.eps = (lr if lr is not None else self.lr), self.betas, self.eps
         o.step_count = 0
-        o._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        o._hyper_ring = torch.zeros(_HYPER_RING, 4, dtype=torch.float32).pin_memory()
+        o._hyper_host = o._hyper_ring[0]
         o._hyper = torch.zeros(4, device=self.flat.device, dtype=torch.float32)
         o.param_groups = [{"lr": o.lr, "params": o.params}]
         return o

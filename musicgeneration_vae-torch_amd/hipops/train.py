@@ -121,6 +121,7 @@ class GraphedPretrainStep:
             raise RuntimeError("GraphedPretrainStep is single-process; use PretrainStep under torch.distributed")
         self.step_obj, self.HF = step, HF
         self.is_pretraining = is_pretraining
+        self._replayed = None
         self.inputs = [t.clone() for t in (note, pre_note, phrase, position)]
         dec = step.gen.decoder
         self.dec = dec
@@ -183,12 +184,17 @@ class GraphedPretrainStep:
         return self._body()
 
     def __call__(self, note, pre_note, phrase, position):
+        # the replayed copy node re-reads ONE pinned row: the previous replay must have read it before it is rewritten
+        if self._replayed is not None:
+            self._replayed.synchronize()
         for dst, src in zip(self.inputs, (note, pre_note, phrase, position)):
             dst.copy_(src, non_blocking=True)
         self._refresh_masks()
         self.step_obj.opt.step_count += 1
         self._set_hyper()
         self.graph.replay()
+        self._replayed = torch.cuda.Event()
+        self._replayed.record()
         return self.loss, self.gen_out
 
 
