@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _seed_per_test(request):
+    """every test draws its random inputs from a seed derived from its own id: results do not depend on which tests
+    ran before it (a borderline tolerance then fails always or never, not once in a while)"""
+    import zlib
+    import torch
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield

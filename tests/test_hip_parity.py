@@ -741,6 +741,7 @@ def test_refiner_d2_fixed_against_oracle():
     from graph.refiner import Refiner
     sd = W.make_state_dict(W.manifest_refiner(), 0, "wc")
     m = Refiner(); m.load_state_dict(sd); m = m.to(dev).train()
+    torch.manual_seed(11)            # (inputs used to depend on what ran before this test)
     x = torch.rand(3, 1, 96, 60)
     osd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else
                (v.clone().double() if v.is_floating_point() else v.clone())) for k, v in sd.items()}
@@ -754,7 +755,9 @@ def test_refiner_d2_fixed_against_oracle():
     check_grad("Refiner dx", xd.grad, xr.grad)
     gscale = max(v.grad.abs().max().item() for v in osd.values() if getattr(v, "grad", None) is not None)
     for n, p in m.named_parameters():
-        check_grad("Refiner d" + n, p.grad, osd[n].grad, atol=1e-6 * gscale)
+        # atol: the conv biases in front of a BatchNorm have an analytically zero gradient; what the kernels return is
+        # the fp32 rounding of a 17 280-term sum that cancels (observed up to 1.3e-6 of the largest gradient)
+        check_grad("Refiner d" + n, p.grad, osd[n].grad, atol=5e-6 * gscale)
     for k, v in m.state_dict().items():
         if "running" in k:
             check("Refiner " + k, v, osd[k])
