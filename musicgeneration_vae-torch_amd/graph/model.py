@@ -58,9 +58,13 @@ class Model(nn.Module):
                 # where the priority stream met more concurrent streams lost 65 % (graph/model_with_gan.py): stay neutral
                 prio = 0
             self._side = torch.cuda.Stream(priority=prio)
-            self._side2 = torch.cuda.Stream()
             HF.register_trunk_stream(self._side)      # joined at the end of every backward pass / before an all-reduce
-            HF.register_trunk_stream(self._side2)
+            # (no stream is created that is not used: streams are dealt onto the four hardware queues in creation
+            # order, and under torch.distributed RCCL's stream should not have to share one -- DESIGN.md 3.5)
+            self._side2 = None
+            if SPLIT_PHRASE:
+                self._side2 = torch.cuda.Stream()
+                HF.register_trunk_stream(self._side2)
         enc = self.phrase_encoder.phrase_encoder
         b = phrase.shape[0]
         if SPLIT_PHRASE and b >= 8 and b % 2 == 0 and not enc.variational:
