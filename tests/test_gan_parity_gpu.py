@@ -1,0 +1,267 @@
+"""GPU suite (-m gpu): the parts of BASELINE.json configs 4-5 that round 1 only smoke-ran, against the oracle.
+
+  * graph.model_with_gan.Model.forward, both modes (reference graph/model_with_gan.py:20-38) vs
+    oracle.restate.generator_gan on both weight sets -- gen, z, pre_z, phrase_feature, gen_z, the 0.3 threshold;
+  * graph.model.Model.forward(is_train=False) and maker_bar.sample (reference graph/model.py:34-41,
+    maker_bar.py:31-44) at 32 songs vs an oracle loop on oracle.restate.generator_sample with injected prior noise;
+  * one train_wae and one train_gan iteration through the AGENT'S OWN methods (agent/barGen_with_gan.py ==
+    reference agent/barGen_with_gan.py:381-537) vs oracle.steps: every loss value, every parameter gradient of every
+    network that steps, BatchNorm running statistics, and the Adam update.
+
+The whole-step oracles are restated from the reference's source text (its agents cannot be imported: SURVEY D1/D3) on
+top of forwards that are pinned bit-for-bit to the reference import (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate as R
+from oracle import steps as S
+from oracle import weights as W
+from parity_util import REPORT, TOL, check, check_grad, flush_report, pop_margins, rel
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _env():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available(), "GPU suite needs a ROCm device"
+    yield
+    flush_report()
+
+
+def _gan_generator(mode):
+    from graph.model_with_gan import Model
+    gsd = W.make_state_dict(W.manifest_generator(), 0, mode)
+    m = Model()
+    m.load_state_dict(gsd)
+    return m.to(dev).eval(), gsd
+
+
+@pytest.mark.parametrize("mode", ["wc", "d4"])
+def test_model_with_gan_forward_both_modes(mode):
+    m, gsd = _gan_generator(mode)
+    g64 = {k: v.double() for k, v in gsd.items()}
+    note, pre, phrase, pos = W.make_inputs(4, seed=77)
+    tol = TOL if mode == "wc" else 7e-3       # d4 decoder: SURVEY section 7 (torch fp32 itself is 2.6e-3 from fp64 there)
+    # ---- is_note=True: the 5-tuple
+    with torch.no_grad():
+        gen, z, pz, pf, gz = m(note.to(dev), pre.to(dev), phrase.to(dev), pos.to(dev))
+        og, oz, opz, opf, ogz = R.generator_gan(g64, note.double(), pre.double(), phrase.double(), pos, True)
+        o32 = R.generator_gan(gsd, note, pre, phrase, pos, True)
+    check("gan-model[%s] z" % mode, z, oz); check("gan-model[%s] pre_z" % mode, pz, opz)
+    check("gan-model[%s] phrase_feature" % mode, pf, opf)
+    check("gan-model[%s] gen (torch fp32 itself: %.2e)" % (mode, rel(o32[0], og)), gen, og, max(tol, 2 * rel(o32[0], og)))
+    # the threshold: bit-exact wherever |gen - 0.3| is outside fp32 noise of the decoder output
+    fake_h = (gen > 0.3).cpu()
+    fake_o = og > 0.3
+    far = (og - 0.3).abs() > max(tol, 2 * rel(o32[0], og)) * og.abs().max()
+    assert torch.equal(fake_h[far], fake_o[far]), "threshold differs away from 0.3"
+    flips = int((fake_h != fake_o).sum())
+    REPORT.append("gan-model[%s] is_note=True: %d of %d cells binarise differently from fp64 (all within noise of 0.3)" % (mode, flips, gen.numel()))
+    # gen_z: the third encoder pass over the binarised bar -- compared on the HIP path's OWN binary bar (exact input)
+    with torch.no_grad():
+        want_gz = R.encoder(g64, "encoder.", fake_h.double())
+    check("gan-model[%s] gen_z = encoder(gen > 0.3)" % mode, gz, want_gz)
+    if flips == 0:
+        check("gan-model[%s] gen_z vs free-running oracle" % mode, gz, ogz)
+    # ---- is_note=False: latent in, 2-tuple out
+    lat = torch.randn(4, 1152, generator=torch.Generator().manual_seed(5)) * 1.5
+    with torch.no_grad():
+        gen2, gz2 = m(lat.to(dev), pre.to(dev), phrase.to(dev), pos.to(dev), False)
+        og2, ogz2 = R.generator_gan(g64, lat.double(), pre.double(), phrase.double(), pos, False)
+        o32b = R.generator_gan(gsd, lat, pre, phrase, pos, False)
+    t2 = max(tol, 2 * rel(o32b[0], og2))
+    check("gan-model[%s] is_note=False gen (torch fp32 itself: %.2e)" % (mode, rel(o32b[0], og2)), gen2, og2, t2)
+    fh2 = (gen2 > 0.3).cpu()
+    far2 = (og2 - 0.3).abs() > t2 * og2.abs().max()
+    assert torch.equal(fh2[far2], (og2 > 0.3)[far2])
+    with torch.no_grad():
+        check("gan-model[%s] is_note=False gen_z" % mode, gz2, R.encoder(g64, "encoder.", fh2.double()))
+
+
+def test_sampling_forward_and_loop_at_32_songs(monkeypatch):
+    """config 5's arithmetic: Model.forward(is_train=False) teacher-forced on the oracle's states, then the whole
+    free-running maker_bar.sample loop (2 phrases x 4 bars, 32 independent songs) on the same prior draws."""
+    import maker_bar
+    from graph.model import Model
+    songs, length = 32, 2
+    gsd = W.make_state_dict(W.manifest_generator(), 0, "wc")
+    gen = Model()
+    gen.load_state_dict(gsd)
+    gen = gen.to(dev).eval()
+    g = torch.Generator().manual_seed(2024)
+    lat = [[torch.randn(songs, 1152, generator=g) for _ in range(4)] for _ in range(length)]
+    want_roll, raw = S.sample_phrases(gsd, lat, length, songs)          # fp32 oracle (the reference's arithmetic)
+    # teacher-forced single calls: the oracle's (binary, hence exact) states in, sigmoid output compared
+    pre_phrase = torch.zeros(songs, 1, 384, 60); pre_bar = torch.zeros(songs, 1, 96, 60)
+    phrase_idx = [330] + list(range(length - 2, -1, -1))
+    n = 0
+    for idx in range(length):
+        pos = torch.full((songs,), phrase_idx[idx], dtype=torch.long)
+        for b in range(4):
+            with torch.no_grad():
+                out = gen(lat[idx][b].to(dev), pre_bar.to(dev), pre_phrase.to(dev), pos.to(dev), False)
+            check("sampling forward phrase %d bar %d (32 songs, teacher-forced)" % (idx, b), out, raw[n])
+            pre_bar = (raw[n] > 0.3).float()
+            n += 1
+        pre_phrase = want_roll[:, idx * 384:(idx + 1) * 384].reshape(songs, 1, 384, 60)
+    # free-running loop on the same draws
+    draws = [t for ph in lat for t in ph]
+    it = iter(draws)
+    monkeypatch.setattr(maker_bar.HF, "randn", lambda shape, sigma=1.0, device="cuda", out=None: next(it).to(device) * sigma)
+    roll = maker_bar.sample(gen, music_length=length, songs=songs, device=dev).cpu()
+    assert tuple(roll.shape) == (songs, length * 384, 60)
+    diff = int((roll != want_roll).sum())
+    REPORT.append("sampling loop 32 songs x %d phrases: %d of %d cells differ from the oracle loop" % (length, diff, roll.numel()))
+    # an autoregressive loop amplifies a single threshold flip (a sigmoid output within fp32 noise of 0.3); none is
+    # expected on the well-conditioned weights, a handful would still be fp32 noise
+    assert diff <= 1e-4 * roll.numel(), diff
+
+
+# ------------------------------------------------------------------------------------------ agent iterations
+def _agent(tmp_path, monkeypatch):
+    from test_agent_gpu import _make_dataset
+    from config import Config
+    from agent.barGen_with_gan import BarGen
+    root = str(tmp_path)
+    _make_dataset(root, n_files=2, per_file=2)
+
+    class Cfg(Config):
+        root_path = root
+        batch_size = 2
+        epoch = 1
+        pretraining_step_size = 0
+        seed = 5
+        log_file = os.path.join(root, "train_epoch.log")
+
+    agent = BarGen(Cfg())
+    sds = {"generator": W.make_state_dict(W.manifest_generator(), 0, "wc"),
+           "discriminator": W.make_state_dict(W.manifest_bar_discriminator(), 0, "wc"),
+           "discriminator_feature": W.make_state_dict(W.manifest_bar_feature_discriminator(), 0, "wc"),
+           "z_discriminator_bar": W.make_state_dict(W.manifest_z_discriminator(), 1, "wc"),
+           "z_discriminator_phrase": W.make_state_dict(W.manifest_z_discriminator(), 2, "wc")}
+    for n, sd in sds.items():
+        getattr(agent, n).load_state_dict(sd)
+    # record the flat gradient of every network at the moment it steps
+    grads = {}
+    for n, net in agent.nets.items():
+        def wrapped(net=net, n=n, orig=net.step):
+            torch.cuda.synchronize()
+            grads[n] = {k: p.grad.detach().clone() for k, p in net.module.named_parameters()}
+            orig()
+        net.step = wrapped
+    return agent, sds, grads
+
+
+def _masks(b, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(b, 1152, generator=g) >= 0.3).float() / 0.7 for _ in range(2)]
+
+
+def _compare_net(tag, module, hip_grads, oracle_grads, ref32_grads, osd, sd0, lr):
+    """gradients of one network at its step (fp64 oracle is the judge, its fp32 run the reference's own arithmetic),
+    then the Adam update the network received"""
+    named = dict(module.named_parameters())
+    gs = max(g.abs().max().item() for g in oracle_grads.values() if g is not None)
+    for n, g in oracle_grads.items():
+        if g is None:
+            assert hip_grads[n].abs().max().item() == 0, (tag, n)
+            continue
+        if g.abs().max().item() <= 1e-6 * gs:
+            continue
+        check_grad("%s d%s" % (tag, n), hip_grads[n], g, 2 * TOL, atol=1e-6 * gs, ref32=ref32_grads[n])
+        # first Adam step: dw = -lr * g / (|g| + eps) -> compare where the gradient is clear of the noise floor
+        big = g.abs() > 1e-3 * g.abs().max()
+        dw_h = (named[n].detach().cpu().double() - sd0[n].double())[big]
+        dw_o = (osd[n].detach() - sd0[n].double())[big]
+        bad = ((dw_h - dw_o).abs() > 0.02 * lr).double().mean().item()
+        assert bad <= 2e-2, (tag, n, bad)
+
+
+def _oracle(kind, sds, lr, batch, noise, masks, dtype):
+    osd = {n: S.leaf_copy(sd, dtype) for n, sd in sds.items()}
+    b = tuple(t.to(dtype) if t.is_floating_point() else t for t in batch)
+    mk = [m.to(dtype) for m in masks]
+    if kind == "wae":
+        opts = {"generator": S.AdamState(osd["generator"], lr), "z_bar": S.AdamState(osd["z_discriminator_bar"], lr),
+                "z_phrase": S.AdamState(osd["z_discriminator_phrase"], lr)}
+        o = S.wae_iteration(osd["generator"], osd["z_discriminator_bar"], osd["z_discriminator_phrase"], opts, b,
+                            [t.to(dtype) for t in noise], mk, True)
+    else:
+        opts = {"generator": S.AdamState(osd["generator"], lr), "discriminator": S.AdamState(osd["discriminator"], lr),
+                "discriminator_feature": S.AdamState(osd["discriminator_feature"], lr)}
+        o = S.gan_iteration(osd["generator"], osd["discriminator"], osd["discriminator_feature"], opts, b, noise.to(dtype), mk, True)
+    return o, osd
+
+
+def test_train_wae_iteration_against_oracle(tmp_path, monkeypatch):
+    agent, sds, grads = _agent(tmp_path, monkeypatch)
+    lr = agent.config.learning_rate
+    batch = W.make_inputs(4, seed=31)
+    g = torch.Generator().manual_seed(8)
+    noise = [torch.randn(4, 1152, generator=g) * agent.config.sigma for _ in range(2)]
+    masks = _masks(4, 3)
+    it = iter(noise)
+    monkeypatch.setattr(agent, "prior", lambda rows, sigma: next(it).to(dev))
+    agent.generator.decoder._drop_masks = [m.to(dev) for m in masks]
+    agent.epoch = 1
+    from metrics import AverageMeter
+    meters = {k: AverageMeter() for k in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+    out = agent.train_wae(*(t.to(dev) for t in batch), meters, 0)          # (epoch + curr_it) % 2 == 1: both halves run
+    torch.cuda.synchronize()
+    o, osd = _oracle("wae", sds, lr, batch, noise, masks, torch.float64)
+    o32, _ = _oracle("wae", sds, lr, batch, noise, masks, torch.float32)
+    check("train_wae phraseZ discriminator loss", meters["z_phrase"].val, o["phrase_loss"])
+    check("train_wae barZ discriminator loss", meters["z_bar"].val, o["bar_loss"])
+    check("train_wae generator loss", meters["generator"].val, o["generator_loss"])
+    check("train_wae returned sample", out, o["gen"][:3], max(TOL, 2e-3))
+    _compare_net("train_wae z_phrase", agent.z_discriminator_phrase, grads["z_discriminator_phrase"], o["grad_z_phrase"],
+                 o32["grad_z_phrase"], osd["z_discriminator_phrase"], sds["z_discriminator_phrase"], lr)
+    _compare_net("train_wae z_bar", agent.z_discriminator_bar, grads["z_discriminator_bar"], o["grad_z_bar"],
+                 o32["grad_z_bar"], osd["z_discriminator_bar"], sds["z_discriminator_bar"], lr)
+    _compare_net("train_wae generator", agent.generator, grads["generator"], o["grad_generator"], o32["grad_generator"], osd["generator"],
+                 sds["generator"], lr)
+    pop_margins("train_wae iteration vs fp64 oracle", 10)
+    assert set(grads) == {"generator", "z_discriminator_bar", "z_discriminator_phrase"}      # nothing else stepped
+    assert agent.opt_discriminator.step_count == 0 and agent.opt_generator.step_count == 1
+
+
+def test_train_gan_iteration_against_oracle(tmp_path, monkeypatch):
+    agent, sds, grads = _agent(tmp_path, monkeypatch)
+    lr = agent.config.learning_rate
+    batch = W.make_inputs(4, seed=32)
+    noise = torch.randn(4, 1152, generator=torch.Generator().manual_seed(9)) * 1.5
+    masks = _masks(4, 4)
+    monkeypatch.setattr(agent, "prior", lambda rows, sigma: noise.to(dev))
+    agent.generator.decoder._drop_masks = [m.to(dev) for m in masks]
+    agent.epoch = 1
+    from metrics import AverageMeter
+    meters = {k: AverageMeter() for k in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+    out = agent.train_gan(*(t.to(dev) for t in batch), meters, 0)
+    torch.cuda.synchronize()
+    o, osd = _oracle("gan", sds, lr, batch, noise, masks, torch.float64)
+    o32, _ = _oracle("gan", sds, lr, batch, noise, masks, torch.float32)
+    check("train_gan bar discriminator loss", meters["discriminator"].val, o["note_loss"])
+    check("train_gan feature discriminator loss", meters["discriminator_feature"].val, o["feature_loss"])
+    check("train_gan generator loss", meters["generator"].val, o["generator_loss"])
+    check("train_gan returned sample", out, o["gen"][:3], max(TOL, 2e-3))
+    _compare_net("train_gan discriminator", agent.discriminator, grads["discriminator"], o["grad_discriminator"],
+                 o32["grad_discriminator"], osd["discriminator"], sds["discriminator"], lr)
+    _compare_net("train_gan discriminator_feature", agent.discriminator_feature, grads["discriminator_feature"],
+                 o["grad_discriminator_feature"], o32["grad_discriminator_feature"], osd["discriminator_feature"], sds["discriminator_feature"], lr)
+    _compare_net("train_gan generator", agent.generator, grads["generator"], o["grad_generator"], o32["grad_generator"], osd["generator"],
+                 sds["generator"], lr)
+    pop_margins("train_gan iteration vs fp64 oracle", 10)
+    # BatchNorm running statistics after THREE train-mode passes (fake, real, generator step) and their counters
+    hsd = agent.discriminator.state_dict()
+    for k, v in osd["discriminator"].items():
+        if "running_" in k:
+            check("train_gan BatchNorm " + k, hsd[k], v)
+        elif k.endswith("num_batches_tracked") and int(v) > 0:
+            assert int(hsd[k]) == int(v) == 3, (k, int(hsd[k]), int(v))
+    assert set(grads) == {"generator", "discriminator", "discriminator_feature"}

@@ -18,8 +18,8 @@ from oracle import restate as R
 from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-3
-REPORT = []
+
+from parity_util import REPORT, TOL, check, check_grad, flush_report, pop_margins, rel
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -35,54 +35,7 @@ def _env():
     assert buf.value.decode().startswith("gfx950"), buf.value
     torch.manual_seed(0)
     yield
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_report.txt", "a") as f:
-        f.write("\n".join(REPORT) + "\n")
-
-
-def rel(a, b):
-    a = a.detach().double().cpu(); b = b.detach().double().cpu()
-    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
-
-
-def check(name, got, want, tol=TOL, atol=0.0):
-    """max|got-want| <= tol * max|want| + atol.  atol is only used for quantities that are
-    analytically ~0 (e.g. the bias gradient of a conv that feeds an InstanceNorm)."""
-    a = got.detach().double().cpu(); b = want.detach().double().cpu()
-    err, scale = (a - b).abs().max().item(), b.abs().max().item()
-    e = err / max(scale, 1e-30)
-    ok = err <= tol * scale + atol
-    REPORT.append("%-70s rel=%.3e abs=%.3e max|ref|=%.3e tol=%.1e atol=%.1e %s" % (name, e, err, scale, tol, atol, "ok" if ok else "FAIL"))
-    assert ok, "%s: abs err %.3e (rel %.3e) > %.1e * %.3e + %.1e" % (name, err, e, tol, scale, atol)
-
-
-def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
-    """Gradient parity that tolerates ReLU/argmax mask flips.  A pre-activation within fp32
-    noise of 0 legitimately takes the other branch than in the fp64 oracle (torch fp32 does
-    the same); that changes a handful of entries by O(1).  Pass when the max-norm criterion
-    holds, or when at most 2 %% of the entries deviate by more than tol * max|ref| and the
-    relative L2 error stays below 5e-2 (a wrong kernel fails both by orders of magnitude)."""
-    a = got.detach().double().cpu(); b = want.detach().double().cpu()
-    err = (a - b).abs(); scale = b.abs().max().item()
-    mx = err.max().item()
-    l2 = ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
-    nbad = int((err > tol * scale + atol).sum().item())
-    frac = nbad / err.numel()
-    ok = mx <= tol * scale + atol or ((frac <= 2e-2 or nbad <= 2) and l2 <= 5e-2)
-    e32 = float("nan")
-    if ref32 is not None:
-        # SURVEY section 7 rule: also fine when within 3x of what torch fp32 (the reference's own
-        # arithmetic) achieves against fp64 -- ill-conditioned quantities (d4 weights, exact ties)
-        e32 = ((ref32.detach().double().cpu() - b).abs().max() / max(scale, 1e-30)).item()
-        ok = ok or mx <= 3 * e32 * scale
-        # a quantity torch fp32 itself misses by > 1 % (the d4 encoder stems' d(bn.bias): a sum of huge
-        # cancelling terms over planes full of exactly tied values) carries no parity information
-        ok = ok or (e32 > 1e-2 and mx <= 10 * e32 * scale)
-    if l2_ok is not None:
-        ok = ok or l2 <= l2_ok
-    REPORT.append("%-70s max-rel=%.3e l2-rel=%.3e outliers=%.2e torch32-vs-fp64=%.3e max|ref|=%.3e %s" % (
-        name, mx / max(scale, 1e-30), l2, frac, e32, scale, "ok" if ok else "FAIL"))
-    assert ok, "%s: max-rel %.3e, l2-rel %.3e, outlier fraction %.2e" % (name, mx / max(scale, 1e-30), l2, frac)
+    flush_report()
 
 
 dev = "cuda"
@@ -552,13 +505,13 @@ def test_train_step_against_oracle_and_golden(golden_dir):
         REPORT.append("  grad %-60s hip-vs-fp64=%.3e torch32-vs-fp64=%.3e |g|=%.3e golden|g|=%.3e" % (
             n, e, e32, params[n].grad.double().norm().item(), gn["grad"][n][0]))
         # whole-step gradients cross ~40 layers of ReLU / max-pool masks: 2e-3 max-norm here,
-        # 1e-3 stays the bar for every kernel and block above
-        # (the sparse binary rolls give the stems planes full of exactly tied values, so the
-        # earliest gradients are chaotic in torch fp32 as well: relative L2 <= 3e-2 also passes)
-        check_grad("step d" + n, params[n].grad, g, 2 * TOL, atol=1e-6 * gscale, ref32=g32, l2_ok=3e-2)
+        # 1e-3 stays the bar for every kernel and block above; beyond that only what torch fp32 itself
+        # misses against fp64 is admitted (parity_util.check_grad)
+        check_grad("step d" + n, params[n].grad, g, 2 * TOL, atol=1e-6 * gscale, ref32=g32)
         assert abs(params[n].grad.double().norm().item() - gn["grad"][n][0]) <= 3e-2 * gn["grad"][n][0] + 1e-6 * gscale, n
     REPORT.append("step: worst max-norm gradient error vs fp64: hip %.3e, torch fp32 itself %.3e (mask flips; see check_grad) over %d tensors" % (
         worst, worst_ref, len(names)))
+    pop_margins("4-bar step vs fp64 oracle", 10)
     for n in gn["unused"]:
         assert params[n].grad.abs().max().item() == 0.0, n
     # Adam step (first step of torch.optim.Adam defaults) applied to the HIP gradients themselves
@@ -605,18 +558,32 @@ def test_full_size_step_parity_and_batch_properties():
         return loss.detach(), gen.detach(), opt.grad.clone()
 
     loss64, gen64, g64 = step(slice(0, B))
-    # (1) the oracle, fp32, same 64 bars
-    osd = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
-    lo, _ = R.pretrain_step_loss(osd, zsd, zsd, note, pre, phrase, pos, True)
+    # (1) the oracle on the same 64 bars: fp64 is the judge, its fp32 run says what the reference's own arithmetic
+    # achieves (rules of parity_util.check_grad: strict 2e-3, else 3 x torch fp32, else flip-tolerant)
     params = dict(m.named_parameters())
-    names = [n for n in params if n in osd]
+    names = [n for n in params if n in gsd]
+    osd = {k: v.clone().double().requires_grad_(True) for k, v in gsd.items()}
+    z64 = {k: v.double() for k, v in zsd.items()}
+    lo, _ = R.pretrain_step_loss(osd, z64, z64, note.double(), pre.double(), phrase.double(), pos, True)
     og = torch.autograd.grad(lo, [osd[n] for n in names], allow_unused=True)
-    check("full-size step loss vs oracle fp32", loss64, lo.detach(), 1e-4)
+    del osd
+    osd32 = {k: v.clone().requires_grad_(True) for k, v in gsd.items()}
+    lo32, _ = R.pretrain_step_loss(osd32, zsd, zsd, note, pre, phrase, pos, True)
+    og32 = torch.autograd.grad(lo32, [osd32[n] for n in names], allow_unused=True)
+    del osd32
+    check("full-size step loss vs oracle fp64", loss64, lo.detach(), 1e-4)
     gscale = max(g.abs().max().item() for g in og if g is not None)
-    for n, g in zip(names, og):
+    pop_margins("(rows before the full-size step)", 0)
+    rules = {}
+    for n, g, g32 in zip(names, og, og32):
         if g is None or g.abs().max().item() <= 1e-6 * gscale:
             continue
-        check_grad("full-size d" + n, params[n].grad, g, 2 * TOL, atol=1e-6 * gscale, l2_ok=3e-2)
+        r = check_grad("full-size d" + n, params[n].grad, g, 2 * TOL, atol=1e-6 * gscale, ref32=g32)
+        rules[r] = rules.get(r, 0) + 1
+    pop_margins("full-size step (64 bars) vs fp64 oracle", 10)
+    REPORT.append("full-size step: admitted by rule: %s" % rules)
+    # most rows must carry information: the uninformative ones (torch fp32 itself > 1 %% off) are the stems' tied planes
+    assert rules.get("uninformative", 0) <= 0.2 * sum(rules.values()), rules
     # (2) per-sample independence
     _, gen4, _ = step(slice(0, 4))
     check("rows 0-3 of the 64-bar forward == the 4-bar forward", gen64[:4], gen4, 1e-4)

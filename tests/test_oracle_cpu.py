@@ -113,3 +113,49 @@ def test_weight_function_is_deterministic_and_has_d4_statistics():
     assert torch.equal(a["layers.0.bn.weight"], torch.ones(64))
     c = W.make_state_dict(W.manifest_encoder(), 1, "d4")
     assert not torch.equal(a["linear.weight"], c["linear.weight"])
+
+
+def test_oracle_agent_iterations_are_consistent_with_the_pinned_pieces():
+    """oracle/steps.py restates whole agent iterations (unpinned as wholes: the reference's agents cannot be imported);
+    here they are tied to the pinned pieces: the generator half of a WAE iteration is exactly the smoothed-loss
+    pre-training step of restate.pretrain_step_loss, frozen networks do not move, stepped ones move by +-lr (first
+    Adam step), the BatchNorm counters of the bar discriminator see its three train-mode passes of a GAN iteration,
+    and the sampling loop is generator_sample applied bar by bar."""
+    from oracle import steps as S
+    B, lr = 2, 0.002
+    sds = {"generator": W.make_state_dict(W.manifest_generator(), 0, "wc"),
+           "discriminator": W.make_state_dict(W.manifest_bar_discriminator(), 0, "wc"),
+           "discriminator_feature": W.make_state_dict(W.manifest_bar_feature_discriminator(), 0, "wc"),
+           "z_bar": W.make_state_dict(W.manifest_z_discriminator(), 1, "wc"),
+           "z_phrase": W.make_state_dict(W.manifest_z_discriminator(), 2, "wc")}
+    batch = W.make_inputs(B, seed=31)
+    g = torch.Generator().manual_seed(8)
+    noise = [torch.randn(B, 1152, generator=g) for _ in range(2)]
+    masks = [(torch.rand(B, 1152, generator=g) >= 0.3).float() / 0.7 for _ in range(2)]
+    osd = {n: S.leaf_copy(sd, torch.float32) for n, sd in sds.items()}
+    opts = {n: S.AdamState(osd[n], lr) for n in ("generator", "z_bar", "z_phrase")}
+    o = S.wae_iteration(osd["generator"], osd["z_bar"], osd["z_phrase"], opts, batch, noise, masks, False)
+    assert "bar_loss" not in o and opts["z_bar"].t == 0 and torch.equal(osd["z_bar"]["net.0.weight"], sds["z_bar"]["net.0.weight"])
+    ref = {k: v.clone().requires_grad_(True) for k, v in sds["generator"].items()}
+    loss, _ = R.pretrain_step_loss(ref, sds["z_bar"], sds["z_phrase"], *batch, False, True, masks)
+    assert abs(loss.item() - o["generator_loss"].item()) <= 1e-6 * abs(loss.item())
+    gw = torch.autograd.grad(loss, ref["decoder.fit1.weight"])[0]
+    assert torch.allclose(gw, o["grad_generator"]["decoder.fit1.weight"], rtol=1e-5, atol=1e-9)
+    moved = (osd["generator"]["decoder.fit1.weight"].detach() - sds["generator"]["decoder.fit1.weight"]).abs().max().item()
+    assert abs(moved - lr) < 1e-5                                                  # first Adam step = -lr * sign(g)
+    assert o["grad_generator"]["decoder.layers.0.bn1.weight"] is None              # defect D5
+    # GAN iteration: three train-mode passes of the bar discriminator, generator and both discriminators step once
+    osd = {n: S.leaf_copy(sd, torch.float32) for n, sd in sds.items()}
+    opts = {n: S.AdamState(osd[n], lr) for n in ("generator", "discriminator", "discriminator_feature")}
+    o = S.gan_iteration(osd["generator"], osd["discriminator"], osd["discriminator_feature"], opts, batch, noise[0] * 1.5, masks, True)
+    assert int(osd["discriminator"]["chord.batch_norm1.num_batches_tracked"]) == 3
+    assert int(osd["discriminator"]["basic.layers.2.bn1.num_batches_tracked"]) == 0           # constructed, never used
+    assert all(opts[n].t == 1 for n in opts) and torch.isfinite(o["generator_loss"])
+    assert o["grad_discriminator"]["linear.weight"].abs().max().item() > 0
+    # sampling loop == generator_sample bar by bar
+    lat = [[torch.randn(1, 1152, generator=g) for _ in range(4)]]
+    roll, raw = S.sample_phrases(sds["generator"], lat, 1, 1)
+    with torch.no_grad():
+        first = R.generator_sample(sds["generator"], lat[0][0], torch.zeros(1, 1, 96, 60), torch.zeros(1, 1, 384, 60), torch.tensor([330]))
+    assert torch.equal(raw[0], first) and torch.equal(roll[0, :96], (first > 0.3).float().view(96, 60))
+    assert tuple(roll.shape) == (1, 384, 60) and set(roll.unique().tolist()) <= {0.0, 1.0}
