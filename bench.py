@@ -17,7 +17,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   algorithmic FLOPs / HIP-event time measured live, per kernel variant,
                   against the 157.3 TFLOP/s dense fp32 matrix peak of MI355X;
   cpu_baseline -- the CPU oracle (a restatement pinned bit-for-bit to the reference import)
-                  running the same step at batch 4 on this host's cores (rank 0, N=1 only).
+                  running the same step on this host's cores (rank 0, N=1 only): batch 64 on all cores
+                  (the GPU's workload), batch 4 on all cores and on 8 threads beside it.
+``value`` is K steps / the barrier-bracketed wall time of the K steps (the driver's contract);
+``ms_per_step_median`` / ``value_median_step`` give SURVEY 8d's median step from per-step events.
 """
 import argparse
 import ctypes
@@ -38,6 +41,7 @@ for p in (ROOT, PKG):
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MATRIX_PEAK_TFLOPS = 2500.0         # dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
 FLOP_PER_BAR_STEP = 29.5e9               # 3 x 9.83 GFLOP forward
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured streaming)
 
 
 def synth_batch(batch, seed, device):
@@ -70,22 +74,20 @@ def log(msg):
 T0 = time.perf_counter()
 
 
-def cpu_baseline(batch=4, min_seconds=12.0, max_steps=60):
-    """the oracle's training step (torch CPU fp32, autograd + Adam) on this host's cores: a bounded sample of about
-    ``min_seconds`` of CPU work after one warm-up step"""
+def _cpu_leg(batch, threads, min_seconds, max_steps, min_steps):
+    """median step time of the oracle's training step (torch CPU fp32, autograd + Adam) after one warm-up step"""
     from oracle import restate as R
     from oracle import weights as W
-    torch.set_num_threads(host_cores())
+    torch.set_num_threads(threads)
     gsd = {k: v.requires_grad_(True) for k, v in W.make_state_dict(W.manifest_generator(), 0, "d4").items()}
     zsd = W.make_state_dict(W.manifest_z_discriminator(), 0, "d4")
-    names = list(gsd)
-    params = [gsd[n] for n in names]
+    params = [gsd[n] for n in gsd]
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
     note, pre, phrase, pos = W.make_inputs(batch, seed=1234)
     times = []
     it = 0
-    while it == 0 or (sum(times) < min_seconds and len(times) < max_steps) or len(times) < 3:
+    while it == 0 or (sum(times) < min_seconds and len(times) < max_steps) or len(times) < min_steps:
         t0 = time.perf_counter()
         loss, _ = R.pretrain_step_loss(gsd, zsd, zsd, note, pre, phrase, pos, True)
         grads = torch.autograd.grad(loss, params, allow_unused=True)
@@ -95,9 +97,21 @@ def cpu_baseline(batch=4, min_seconds=12.0, max_steps=60):
             times.append(time.perf_counter() - t0)
         it += 1
     dt = float(np.median(times))
-    return {"value": batch / dt, "unit": "bars/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": batch / dt, "unit": "bars/s", "cores": torch.get_num_threads(), "batch": batch,
             "sample": "%d timed steps = %.1f s of CPU work (after 1 warm-up) of the same pre-training step at batch %d, fp32, "
                       "torch %s CPU; median step" % (len(times), sum(times), batch, torch.__version__)}
+
+
+def cpu_baseline():
+    """the oracle's training step on this host's cores, a bounded sample: the headline leg runs the GPU's own
+    workload (batch 64) on every core of the box's share; beside it the reference's operating scale (batch 4, BASELINE.json
+    configs[0]) on all cores and on 8 threads (the survey container's thread count)."""
+    n = host_cores()
+    main = _cpu_leg(64, n, 15.0, 3, 2)
+    main["kind"] = "port"
+    main["batch4"] = _cpu_leg(4, n, 6.0, 30, 3)
+    main["batch4_8_threads"] = _cpu_leg(4, min(8, n), 6.0, 30, 3)
+    return main
 
 
 def pmc_record(kernel):
@@ -120,8 +134,8 @@ def pmc_record(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="bars per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_bf16x3"],
                     help="matrix-operand precision of the conv kernels; f32 is BASELINE.json's metric config (configs[1]), "
@@ -157,6 +171,7 @@ def main():
     from hipops import _native as nat
     from hipops import functional as HF
     from hipops.train import PretrainStep
+    from hipops import dist as hdist
     from graph.model import Model
     from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
     from graph.loss.bar_loss import Loss, DLoss
@@ -174,6 +189,7 @@ def main():
             p.requires_grad = False
     HF.manual_seed(1234, rank)
     step = PretrainStep(gen, zb, zp, Loss().to(dev), DLoss(), lr=0.002)
+    step_transport = step.reducer.transport if world > 1 else None
     batch = synth_batch(args.batch, 1234 + rank, dev)
     eager_step = step
     if args.graph:
@@ -199,9 +215,12 @@ def main():
         step(*batch)
     sync_all()
     log("timing %d steps" % args.steps)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step boundaries on the step's stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss, _ = step(*batch)
+        marks[i + 1].record()
     t_host = time.perf_counter() - t0       # the host's share: time to ENQUEUE the steps (it runs ahead of the GPU)
     sync_all()
     dt = time.perf_counter() - t0
@@ -211,7 +230,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
-    log("timed region: %.1f ms/step" % (1e3 * dt / args.steps))
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    med_ms = step_ms[len(step_ms) // 2] if args.steps % 2 else 0.5 * (step_ms[args.steps // 2 - 1] + step_ms[args.steps // 2])
+    if world > 1:
+        t = torch.tensor([med_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med_ms = float(t.item())
+    log("timed region: %.2f ms/step (mean over the region), %.2f ms median step" % (1e3 * dt / args.steps, med_ms))
 
     roof = None
     if not args.no_roofline and rank != 0:
@@ -236,15 +261,21 @@ def main():
         eager_step(*batch)           # per-launch events need real launches (not a graph replay)
         torch.cuda.synchronize()
         HF.FORK_WGRAD, HF.FORK_BRANCHES, gm.OVERLAP_TRUNKS = saved
-        recs = (nat.ProfRec * 40)()
-        n = L.mgvae_prof_collect(recs, 40)
+        recs = (nat.ProfRec * 64)()
+        n = L.mgvae_prof_collect(recs, 64)
         L.mgvae_prof_enable(0)
         L.mgvae_prof_detail(b"")
+        conv = [r for r in recs[:n] if r.kind < 5]
+        # the HBM-bound kernels (flat Adam, InstanceNorm): `flops` carries their ALGORITHMIC bytes (include/mgvae.h)
+        hbm = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,
+                "avg_us": 1e3 * r.ms / r.launches, "achieved": r.flops / (r.ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": r.flops / (r.ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": r.flops / r.launches} for r in recs[:n] if r.kind >= 5]
         fam = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,
-                "avg_us": 1e3 * r.ms / r.launches, "tflops": r.flops / (r.ms * 1e-3) / 1e12} for r in recs[:n]]
+                "avg_us": 1e3 * r.ms / r.launches, "tflops": r.flops / (r.ms * 1e-3) / 1e12} for r in conv]
         fam.sort(key=lambda f: -f["ms"])
         tot_ms = sum(f["ms"] for f in fam)
-        tot_fl = sum(r.flops for r in recs[:n])
+        tot_fl = sum(r.flops for r in conv)
         top = fam[0]
         pmc = pmc_record(top["kernel"])
         roof = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": peak,
@@ -258,7 +289,8 @@ def main():
                 "all_conv_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
                                      "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
                                      "share_of_step_time": tot_ms / (1e3 * dt / args.steps)},
-                "variants": fam}
+                "variants": fam,
+                "hbm": hbm}
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline on %d cores" % host_cores())
@@ -270,11 +302,14 @@ def main():
         out = {
             "metric": "bars/sec VAE training step (fwd+bwd+opt) at 1/2/4/8 MI355X", "value": value, "unit": "bars/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_median": med_ms, "value_median_step": args.batch * world / (med_ms * 1e-3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "barGen2 pre-training generator step: PhraseEncoder + 2x Encoder + Decoder fwd, 3 frozen "
                                    "z-discriminators, Loss, bwd, Adam; Refiner excluded (reference defect D2)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hip_graph": bool(args.graph),
+                       "rccl_ranks": {"world_size": world, "backend": hdist.backend_name()},
+                       "grad_transport": step_transport,
                        "weights": "weights_init (D4) random", "device": arch.value.decode(), "cus": cus.value},
             "step_tflops": value * FLOP_PER_BAR_STEP / 1e12, "loss": final_loss,
             "roofline": roof, "cpu_baseline": base,

@@ -253,11 +253,22 @@ int mgvae_unpack_bits(const unsigned char* packed, float* out, size_t nbits, voi
 int mgvae_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                     float eps, float grad_scale, void* stream);
 
+/* ---- bf16 gradient transport of the data-parallel exchange (replaces the per-tensor Horovod all-reduce of
+ * agent/barGen_horovod.py:91-99): the flat fp32 gradient is rounded to bf16 (RNE) for the wire, the `R` addends that
+ * arrive at a rank are summed in fp32 in rank order and rounded once, the reduced bucket is expanded back to fp32.
+ * bf16 buffers are passed as void* (2 bytes per element, 8-byte aligned); n of mgvae_bf16_rows_sum a multiple of 4. */
+int mgvae_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+int mgvae_bf16_to_f32(const void* src_bf16, float* dst, size_t n, void* stream);
+int mgvae_bf16_rows_sum(const void* rows_bf16, void* dst_bf16, int R, size_t n, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ----------------------------------------
  * When enabled, every mgvae_conv2d_* launch is bracketed by hipEvents on its stream and
  * its algorithmic FLOPs are recorded.  mgvae_prof_collect synchronises the events and
  * returns per-kernel-variant totals: up to `cap` records of
- * {kind (0 fwd,1 bwd_data,2 bwd_weight igemm; 3 fwd,4 bwd_data direct), tile id, launches, total ms, total flops}.    */
+ * {kind (0 fwd,1 bwd_data,2 bwd_weight igemm; 3 fwd,4 bwd_data direct), tile id, launches, total ms, total flops}.
+ * Kinds 5..7 are the HBM-bound kernels (flat Adam, InstanceNorm forward / backward): their `flops` field carries the
+ * ALGORITHMIC BYTES of the launch instead (Adam 7 x 4n; InstanceNorm 2 x / 3 x 4 N C P).                              */
+enum { MGVAE_PROF_ADAM = 5, MGVAE_PROF_INORM_FWD = 6, MGVAE_PROF_INORM_BWD = 7, MGVAE_PROF_KINDS = 8 };
 typedef struct MgvaeProfRec { int32_t kind, tile, launches; double ms, flops; } MgvaeProfRec;
 int mgvae_prof_enable(int on);
 int mgvae_prof_collect(MgvaeProfRec* out, int cap);

@@ -103,12 +103,13 @@ class Net:
 
     def load_state_dict(self, sd):
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
-        missing = self.module.load_state_dict(sd, strict=False)
-        bad = [k for k in missing.missing_keys if not k.startswith("refiner.")]
+        # parameters are views of the flat buffer and load_state_dict copies in place, so the flat buffer follows.
+        # Only the refiner's entries may be absent or surplus (reference checkpoints carry them; this build's default
+        # generator has no refiner): anything else is a checkpoint of another layout
+        res = self.module.load_state_dict(sd, strict=False)
+        bad = [k for k in list(res.missing_keys) + list(res.unexpected_keys) if not k.startswith("refiner.")]
         if bad:
-            raise RuntimeError("checkpoint is missing %s" % bad[:5])
-        with torch.no_grad():   # parameters are views of the flat buffer: load_state_dict copied in place
-            pass
+            raise RuntimeError("checkpoint does not match the network: %s" % bad[:5])
 
 
 class AgentBase(object):
@@ -129,8 +130,10 @@ class AgentBase(object):
         self.logger = self.set_logger()
         self.iteration = 0
         self.epoch = 0
-        seed = getattr(self.config, "seed", None)
-        self.manual_seed = seed if seed is not None else random.randint(1, 10000)
+        # one seed for the whole job: with config.seed = None rank 0 draws it (reference agent/barGen2.py:53) and
+        # broadcasts it, so python's ``random`` (agent/barGen.py's per-epoch div_flag) and torch's host RNG agree on
+        # every rank and all ranks take the same branches, i.e. issue the same collectives in the same order
+        self.manual_seed = hdist.shared_seed(getattr(self.config, "seed", None))
 
     # ---------------------------------------------------------------- reference surface
     def get_lr(self, optimizer):

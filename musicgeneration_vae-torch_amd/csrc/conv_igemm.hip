@@ -1873,8 +1873,8 @@ extern "C" int mgvae_prof_detail(const char* path) {
 
 extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    MgvaeProfRec recs[35];
-    for (int k = 0; k < 5; ++k)
+    MgvaeProfRec recs[MGVAE_PROF_KINDS * 7];
+    for (int k = 0; k < MGVAE_PROF_KINDS; ++k)
         for (int t = 0; t < 7; ++t) recs[k * 7 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
     for (auto& pe : g_prof_entries) {
         float ms = 0.f;
@@ -1882,7 +1882,7 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
         MgvaeProfRec& r = recs[pe.kind * 7 + pe.tile];
         r.launches += 1; r.ms += ms; r.flops += pe.flops;
-        if (g_prof_detail) {
+        if (g_prof_detail && pe.kind < 5) {
             const IgemmP& q = pe.p;
             fprintf(g_prof_detail, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%u,%u,%u,%.1f,%.3f,%.2f\n", pe.kind, pe.tile, q.N, q.Cx,
                     q.H, q.W, q.Cy, q.OH, q.OW, q.KH, q.KW, q.SH, q.SW, pe.gx, pe.gy, pe.gz, ms * 1e3, pe.flops * 1e-9,
@@ -1893,7 +1893,7 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     g_prof_entries.clear();
     if (g_prof_detail) fflush(g_prof_detail);
     int n = 0;
-    for (int i = 0; i < 35 && n < cap; ++i)
+    for (int i = 0; i < MGVAE_PROF_KINDS * 7 && n < cap; ++i)
         if (recs[i].launches > 0) out[n++] = recs[i];
     return n;
 }
@@ -1901,6 +1901,9 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
     static char buf[5][7][48];
+    if (kind == MGVAE_PROF_ADAM) return "adam_kernel";
+    if (kind == MGVAE_PROF_INORM_FWD) return "instance_norm_fwd_*";
+    if (kind == MGVAE_PROF_INORM_BWD) return "instance_norm_bwd_*";
     if (kind < 0 || kind > 4 || tile < 0 || tile > 6) return "?";
     if (tile == 5) snprintf(buf[kind][tile], 48, kind == 2 ? "skinny_wgrad_kernel" : "skinny_gemm_kernel (%s)", kind == 0 ? "fwd" : "bwd_data");
     else if (tile == 6) snprintf(buf[kind][tile], 48, kind == 2 ? "thin_bwd_weight_kernel" : "thin_fwd_kernel");

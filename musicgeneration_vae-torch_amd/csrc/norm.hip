@@ -526,6 +526,8 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
     if (y_coff < 0 || y_coff + C > y_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    void* prof_tok = nullptr;      // measurement hook (bench.py roofline.hbm): algorithmic bytes = read x + write y
+    mgvae_prof_record_begin(MGVAE_PROF_INORM_FWD, 0, 2.0 * 4.0 * (double)NC * P, stream, &prof_tok);
 #define MGVAE_INF(NV) hipLaunchKernelGGL((instance_norm_fwd_vec_kernel<NV, 1>), dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
                                          gamma, beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx)
     if (P <= 24) {
@@ -548,6 +550,7 @@ extern "C" int mgvae_instance_norm_fwd(const float* x, const float* gamma, const
                                beta, y, stats, NC, C, P, y_ctot, y_coff, eps, act, slope, pool_avg, pool_max, pool_idx);
     }
 #undef MGVAE_INF
+    mgvae_prof_record_end(prof_tok, stream);
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }
@@ -561,6 +564,8 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
     if (dy_coff < 0 || dy_coff + C > dy_ctot || act == MGVAE_ACT_SIGMOID) return MGVAE_EINVAL;
     const int NC = N * C;
     const bool al = ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    void* prof_tok = nullptr;      // algorithmic bytes = read x + read dy + write dx
+    mgvae_prof_record_begin(MGVAE_PROF_INORM_BWD, 0, 3.0 * 4.0 * (double)NC * P, stream, &prof_tok);
 #define MGVAE_INB(NV) hipLaunchKernelGGL((instance_norm_bwd_vec_kernel<NV, 1>), dim3(cdiv(NC, 4)), dim3(256), 0, as_stream(stream), x, \
                                          gamma, beta, stats, dy, dx, dgamma, dbeta, NC, C, P, dy_ctot, dy_coff, act, slope, add_const, \
                                          add_point, add_index)
@@ -587,6 +592,7 @@ extern "C" int mgvae_instance_norm_bwd(const float* x, const float* gamma, const
                                add_point, add_index);
     }
 #undef MGVAE_INB
+    mgvae_prof_record_end(prof_tok, stream);
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }

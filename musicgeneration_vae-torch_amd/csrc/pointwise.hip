@@ -502,8 +502,73 @@ extern "C" int mgvae_adam_step(float* p, const float* g, float* m, float* v, siz
                                float grad_scale, void* stream) {
     if (!p || !g || !m || !v || !hyper || n == 0) return MGVAE_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MGVAE_EINVAL;
+    void* prof_tok = nullptr;      // measurement hook (bench.py roofline.hbm): reads p, g, m, v and writes p, m, v
+    mgvae_prof_record_begin(MGVAE_PROF_ADAM, 0, 7.0 * 4.0 * (double)n, stream, &prof_tok);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(256), 0, as_stream(stream), p, g, m, v, n, hyper,
                        eps, grad_scale);
+    mgvae_prof_record_end(prof_tok, stream);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
+// ---- bf16 gradient transport of the data-parallel exchange (hipops/dist.py, transport "bf16") ----------------------
+// The flat fp32 gradient travels as bf16 and is summed in fp32 where it arrives; HBM-bound streaming kernels, 8 values
+// per lane and instruction on the fp32 side.
+typedef __bf16 bf16x4_pw __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        bf16x4_pw o;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;     // round to nearest even
+        reinterpret_cast<bf16x4_pw*>(dst)[i] = o;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) dst[i] = (__bf16)src[i];
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const bf16x4_pw v = reinterpret_cast<const bf16x4_pw*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) dst[i] = (float)src[i];
+}
+// dst[j] = bf16( sum_r rows[r][j] ), the sum in fp32 in rank order (deterministic); n a multiple of 4
+__global__ __launch_bounds__(256) void bf16_rows_sum_kernel(const __bf16* __restrict__ rows, __bf16* __restrict__ dst, int R,
+                                                            size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const bf16x4_pw v = reinterpret_cast<const bf16x4_pw*>(rows + (size_t)r * n)[i];
+            a0 += (float)v[0]; a1 += (float)v[1]; a2 += (float)v[2]; a3 += (float)v[3];
+        }
+        bf16x4_pw o;
+        o[0] = (__bf16)a0; o[1] = (__bf16)a1; o[2] = (__bf16)a2; o[3] = (__bf16)a3;
+        reinterpret_cast<bf16x4_pw*>(dst)[i] = o;
+    }
+}
+
+extern "C" int mgvae_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+    if (!src || !dst || n == 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(256), 0, as_stream(stream), src,
+                       static_cast<__bf16*>(dst), n);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+extern "C" int mgvae_bf16_to_f32(const void* src, float* dst, size_t n, void* stream) {
+    if (!src || !dst || n == 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 7)) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(256), 0, as_stream(stream),
+                       static_cast<const __bf16*>(src), dst, n);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+extern "C" int mgvae_bf16_rows_sum(const void* rows, void* dst, int R, size_t n, void* stream) {
+    if (!rows || !dst || R <= 0 || n == 0 || (n & 3) || ((uintptr_t)rows & 7) || ((uintptr_t)dst & 7)) return MGVAE_EINVAL;
+    hipLaunchKernelGGL(bf16_rows_sum_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(256), 0, as_stream(stream),
+                       static_cast<const __bf16*>(rows), static_cast<__bf16*>(dst), R, n);
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }

@@ -81,6 +81,9 @@ SIGNATURES = {
     "mgvae_reparam_kl_fwd": (c_int, [P, P, P, P, P, P, c_size_t, P]),
     "mgvae_reparam_kl_bwd": (c_int, [P, P, P, P, P, P, P, c_size_t, P]),
     "mgvae_adam_step": (c_int, [P, P, P, P, c_size_t, P, c_float, c_float, P]),
+    "mgvae_f32_to_bf16": (c_int, [P, P, c_size_t, P]),
+    "mgvae_bf16_to_f32": (c_int, [P, P, c_size_t, P]),
+    "mgvae_bf16_rows_sum": (c_int, [P, P, c_int, c_size_t, P]),
     "mgvae_prof_enable": (c_int, [c_int]),
     "mgvae_prof_collect": (c_int, [ctypes.POINTER(ProfRec), c_int]),
     "mgvae_prof_detail": (c_int, [ctypes.c_char_p]),

@@ -220,8 +220,19 @@ _wgrad_rr = [0]
 _join_queued = [-1]      # id of the autograd graph task that already has the join callback queued
 
 
+def _shared_sides():
+    """under torch.distributed ONE weight-gradient stream serves every forking stream: main + phrase trunk + that
+    stream are then the only compute streams beside RCCL's own (a fifth busy stream shares a hardware
+    queue with another one and the step falls off a cliff, 23.9 -> 36 ms).  MGVAE_SHARED_WGRAD=0/1 overrides."""
+    v = _os.environ.get("MGVAE_SHARED_WGRAD")
+    if v is not None:
+        return v != "0"
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def side_stream_of(cur, slot=0):
-    key = (cur.device.index, cur.cuda_stream, slot)
+    key = (cur.device.index, 0 if (slot >= 2 and _shared_sides()) else cur.cuda_stream, slot)
     st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=cur.device)
@@ -240,25 +251,35 @@ def register_trunk_stream(st):
         _trunk_streams.append(st)
 
 
-def _join_sides(slot=None):
+def _join_sides(slot=None, parent=None):
     """make the caller's stream wait for every side stream used since the last join (end of a backward pass);
-    ``slot``: only the side streams of that slot"""
+    ``slot``: only the side streams of that slot; ``parent``: only the side streams forked from that stream (and no
+    trunk stream): what an early gradient bucket launched from the step's main stream has to wait for"""
     cur = torch.cuda.current_stream()
-    if slot is None:
+    if slot is None and parent is None:
         for st in _trunk_streams:
             if st.device == cur.device and st.cuda_stream != cur.cuda_stream:
                 cur.wait_stream(st)
     for key in list(_used_sides):
-        st, sl = _used_sides[key]
-        if slot is None or sl == slot:
+        st, sl, par = _used_sides[key]
+        if (slot is None or sl == slot) and (parent is None or par is None or par == parent.cuda_stream):
             cur.wait_stream(st)
             del _used_sides[key]
-    if slot is None:
+    if slot is None and parent is None:
         _join_queued[0] = -1
 
 
-def join_side_streams(slot=None):
-    _join_sides(slot)
+def join_side_streams(slot=None, parent=None):
+    _join_sides(slot, parent)
+
+
+def live_streams():
+    """every stream this module has created (side streams of forked work, registered trunk streams): the data-parallel
+    step asserts their number at start-up (more concurrent streams than hardware queues is a cliff)"""
+    seen = {}
+    for st in list(_side_streams.values()) + list(_trunk_streams):
+        seen[st.cuda_stream] = st
+    return list(seen.values())
 
 
 def _ensure_join_callback():
@@ -283,7 +304,7 @@ class _forked:
         for t in self.tensors:
             if t is not None:
                 t.record_stream(side)
-        _used_sides[id(side)] = (side, self.slot)
+        _used_sides[id(side)] = (side, self.slot, None if (self.slot >= 2 and _shared_sides()) else cur.cuda_stream)
         _ensure_join_callback()      # once per backward pass (keyed by task: survives an aborted pass)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()

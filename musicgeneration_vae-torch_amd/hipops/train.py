@@ -26,6 +26,7 @@ class PretrainStep:
         self.opt = FlatParams(list(generator.parameters()), lr=lr)
         hdist.broadcast_flat(self.opt.flat)
         self.reducer = GradReducer(self.opt.grad, bucket_elems)
+        self._steps_checked = 0
         # flat range of the decoder (the bulk of the gradient, finished first in backward)
         ids = {id(p): i for i, p in enumerate(self.opt.params)}
         dec = [ids[id(p)] for p in generator.decoder.parameters()]
@@ -44,6 +45,10 @@ class PretrainStep:
     def _arm_overlap(self, tensors):
         """when the gradients of all decoder INPUTS have been produced, every decoder
         parameter gradient is already enqueued: start its all-reduce"""
+        enc = getattr(self.gen, "encoder", None)
+        t_in = getattr(enc, "trunk_input", None) if enc is not None else None
+        if enc is not None:
+            enc.trunk_input = None          # one step's tensor: do not keep its autograd graph alive between steps
         if not hdist.is_dist():
             return
         state = {"left": len(tensors)}
@@ -51,15 +56,17 @@ class PretrainStep:
         def fire(_g):
             state["left"] -= 1
             if state["left"] == 0:
-                self.reducer.reduce_range(*self.dec_range)
+                self.reducer.reduce_range(*self.dec_range, early=True)
 
         for t in tensors:
             t.register_hook(fire)
-        # second early bucket: the bar-encoder trunk, while the (twice as long) phrase trunk is still in backward
-        enc = getattr(self.gen, "encoder", None)
-        t_in = getattr(enc, "trunk_input", None) if enc is not None else None
-        if self.enc_range is not None and t_in is not None:
-            t_in.register_hook(lambda _g: self.reducer.reduce_range(*self.enc_range))
+        # second early bucket: the bar-encoder trunk, while the (twice as long) phrase trunk is still in backward.
+        # Only when BOTH bar-encoder passes ran as the one stacked pass whose trunk input ``t_in`` is: with two
+        # separate passes (variational encoder, unequal shapes) the attribute holds the last pass only, and the other
+        # pass would still be accumulating into the range while it is being reduced.
+        z, pre_z = tensors[0], tensors[1]
+        if self.enc_range is not None and t_in is not None and _stacked(z, pre_z) is not None:
+            t_in.register_hook(lambda _g: self.reducer.reduce_range(*self.enc_range, early=True))
 
     def forward_loss(self, note, pre_note, phrase, position, is_pretraining=True):
         """generator forward + the four loss terms.  The three frozen z-discriminator passes depend only on the
@@ -91,6 +98,8 @@ class PretrainStep:
         return loss, gen, (z, pre_z, pf)
 
     def __call__(self, note, pre_note, phrase, position, is_pretraining=True):
+        if self.opt.grad.is_cuda:
+            self.reducer.main_stream = torch.cuda.current_stream()
         self.opt.zero_grad()
         loss, gen, latents = self.forward_loss(note, pre_note, phrase, position, is_pretraining)
         self._arm_overlap(latents)
@@ -98,6 +107,15 @@ class PretrainStep:
         self.reducer.reduce_rest()
         self.reducer.wait()
         self.opt.step(grad_scale=1.0 / hdist.world_size())
+        if hdist.is_dist() and self._steps_checked < 2:
+            # start-up check: main + phrase trunk + ONE weight-gradient stream (+ the bf16 transport's communication
+            # stream when that is on) beside RCCL's own -- never a fifth busy stream
+            from . import functional as HF
+            self._steps_checked += 1
+            n = len(HF.live_streams())
+            if n > 2:
+                raise RuntimeError("data-parallel step created %d side streams (expected <= 2: phrase trunk + one "
+                                   "weight-gradient stream)" % n)
         return loss, gen
 
 
@@ -129,13 +147,23 @@ class GraphedPretrainStep:
         self.masks = [torch.ones(B, 1152, device=note.device), torch.ones(B, 1152, device=note.device)]
         self._ones = torch.ones(B, 1152, device=note.device)
         self.use_masks = dec.training and dec.dropout_p > 0.0
+        # the eager warm-up (conv gather tables, autotuner, allocator) runs real optimizer steps: the parameters, both
+        # Adam moments and the step counter are restored afterwards, so constructing the object trains nothing
+        opt = step.opt
+        saved = (opt.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up on a side stream, as torch's capture recipe asks
             for _ in range(warmup):
                 self._eager()
+                # pinned row 0 of the Adam scalars is rewritten by the next warm-up step: its H2D copy must have read it
+                torch.cuda.current_stream().synchronize()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            opt.flat.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
+        opt.step_count = saved[3]
+        del saved
         self.graph = torch.cuda.CUDAGraph()
         self._refresh_masks()
         self._set_hyper()                              # capture records, it does not execute: no step is consumed

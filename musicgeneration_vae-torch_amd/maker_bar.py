@@ -20,7 +20,15 @@ def load_generator(config, device, use_refiner=False):
     path = os.path.join(config.root_path, config.checkpoint_dir, config.checkpoint_file)
     ck = torch.load(path, map_location=device, weights_only=False)
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ck["generator_state_dict"].items()}
-    gen.load_state_dict(sd, strict=False)
+    # a checkpoint in another layout must not silently leave the generator at its random initialisation: only the
+    # refiner's entries may be absent (checkpoints of this build's default, refiner-less generator) or surplus
+    # (reference checkpoints loaded into it) -- the rule of agent/base.py::Net.load_state_dict
+    res = gen.load_state_dict(sd, strict=False)
+    missing = [k for k in res.missing_keys if not k.startswith("refiner.")]
+    unexpected = [k for k in res.unexpected_keys if not k.startswith("refiner.")]
+    if missing or unexpected:
+        raise RuntimeError("checkpoint %s does not match the generator: missing %s, unexpected %s"
+                           % (path, missing[:5], unexpected[:5]))
     return gen
 
 

@@ -40,6 +40,24 @@ def _worker(rank, world, port, q):
         ok = ok and torch.equal(w, torch.zeros(10))
         mean = hd.all_reduce_mean_scalar(float(rank + 1))
         ok = ok and abs(mean - (sum(r + 1 for r in range(world)) / world)) < 1e-12
+        # the job's seed: drawn on rank 0 when the config has none, identical everywhere (each rank's own python RNG
+        # is seeded differently here, as unseeded processes are)
+        import random
+        random.seed(1000 + rank)
+        seeds = [None] * world
+        dist.all_gather_object(seeds, hd.shared_seed(None))
+        ok = ok and len(set(seeds)) == 1 and 1 <= seeds[0] <= 10000 and hd.shared_seed(77) == 77
+        # bf16 gradient transport: all-to-all of bf16 shards, fp32 sum on arrival, all-gather; ragged bucket sizes
+        gen = torch.Generator().manual_seed(5 + rank)
+        gb = torch.randn(n, generator=gen)
+        parts = [torch.randn(n, generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+        want_bf = sum(p.bfloat16().float() for p in parts).bfloat16().float()      # one rounding per addend, one per sum
+        red3 = hd.GradReducer(gb, bucket_elems=5000, transport="bf16")
+        red3.reduce_range(12800, 51200, early=True)
+        red3.reduce_rest(); red3.wait()
+        ok = ok and torch.equal(gb, want_bf)
+        ok = ok and float((gb - sum(parts)).norm() / sum(parts).norm()) < 6e-3
+        assert hd.backend_name() == "gloo"
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -940,8 +940,12 @@ def test_graphed_train_step_matches_eager():
     for _ in range(5):
         le, _ = eager(*batch)
     graphed_base = build()
+    w_before = graphed_base.opt.flat.clone()
     gs = GraphedPretrainStep(graphed_base, *batch, warmup=3)
-    for _ in range(2):
+    # construction trains nothing: the warm-up steps are undone (weights, Adam moments, step counter)
+    assert torch.equal(graphed_base.opt.flat, w_before) and graphed_base.opt.step_count == 0
+    assert float(graphed_base.opt.exp_avg.abs().max()) == 0.0
+    for _ in range(5):
         lg, _ = gs(*batch)
     assert graphed_base.opt.step_count == eager.opt.step_count == 5
     a, b = eager.opt.flat.double().cpu(), graphed_base.opt.flat.double().cpu()
