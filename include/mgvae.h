@@ -109,6 +109,19 @@ int mgvae_conv2d_fwd_masked(const MgvaeConvDesc* d, const float* x, const float*
 int mgvae_conv2d_bwd_data_masked(const MgvaeConvDesc* d, const float* y, const float* w, int w_transposed,
                                  const float* bias, float* x, const MgvaeActMask* mask, void* stream);   /* mask over X */
 
+/* ---- channels-last (NHWC) family: the same three products on tensors stored [N, H, W, C] (x_ctot / y_ctot are then the
+ * channel pitch of a pixel row) and weights stored [Cy, KH, KW, Cx] -- torch.channels_last for activations AND weights,
+ * so logical shapes and state_dict entries are unchanged.  K = (tap, channel) is contiguous in memory for both forward
+ * operands: 16-byte loads, no per-element gather arithmetic, no per-step weight repacking (csrc/conv_nhwc.inc).
+ * Replaces the same reference calls as the NCHW entry points above (graph/encodingBlock.py:87-126 for the encoder
+ * trunks).  Channel counts and slice offsets must be multiples of 16 / 4.  `mask` (nullable): epilogue factor act'(mask)
+ * as in the *_masked entry points.                                                                                      */
+int mgvae_conv2d_nhwc_fwd(const MgvaeConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                          const MgvaeActMask* mask, void* stream);
+int mgvae_conv2d_nhwc_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias, float* x,
+                               const MgvaeActMask* mask, void* stream);
+int mgvae_conv2d_nhwc_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw, void* stream);
+
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                             void* stream);
 /* Faster path of the two calls above: direct (halo-tile) convolution with pre-packed weights.
@@ -267,8 +280,9 @@ int mgvae_bf16_rows_sum(const void* rows_bf16, void* dst_bf16, int R, size_t n, 
  * returns per-kernel-variant totals: up to `cap` records of
  * {kind (0 fwd,1 bwd_data,2 bwd_weight igemm; 3 fwd,4 bwd_data direct), tile id, launches, total ms, total flops}.
  * Kinds 5..7 are the HBM-bound kernels (flat Adam, InstanceNorm forward / backward): their `flops` field carries the
- * ALGORITHMIC BYTES of the launch instead (Adam 7 x 4n; InstanceNorm 2 x / 3 x 4 N C P).                              */
-enum { MGVAE_PROF_ADAM = 5, MGVAE_PROF_INORM_FWD = 6, MGVAE_PROF_INORM_BWD = 7, MGVAE_PROF_KINDS = 8 };
+ * ALGORITHMIC BYTES of the launch instead (Adam 7 x 4n; InstanceNorm 2 x / 3 x 4 N C P).
+ * Kinds 8..10: the channels-last implicit-GEMM kernels (forward, data gradient, weight gradient).                       */
+enum { MGVAE_PROF_ADAM = 5, MGVAE_PROF_INORM_FWD = 6, MGVAE_PROF_INORM_BWD = 7, MGVAE_PROF_NHWC_FWD = 8, MGVAE_PROF_KINDS = 11 };
 typedef struct MgvaeProfRec { int32_t kind, tile, launches; double ms, flops; } MgvaeProfRec;
 int mgvae_prof_enable(int on);
 int mgvae_prof_collect(MgvaeProfRec* out, int cap);

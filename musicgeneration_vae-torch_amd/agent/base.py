@@ -122,6 +122,7 @@ class AgentBase(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
             raise RuntimeError("the BarGen agents of this build need a ROCm GPU (no CPU fallback for the HIP hot path)")
+        self.local_rank %= max(1, torch.cuda.device_count())     # tests stack several gloo ranks on the one GPU of a box
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank)
         if self.world > 1 and not torch.distributed.is_initialized():

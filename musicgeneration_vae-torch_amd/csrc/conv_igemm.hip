@@ -1882,7 +1882,7 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
         MgvaeProfRec& r = recs[pe.kind * 7 + pe.tile];
         r.launches += 1; r.ms += ms; r.flops += pe.flops;
-        if (g_prof_detail && pe.kind < 5) {
+        if (g_prof_detail && (pe.kind < 5 || pe.kind >= MGVAE_PROF_NHWC_FWD)) {
             const IgemmP& q = pe.p;
             fprintf(g_prof_detail, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%u,%u,%u,%.1f,%.3f,%.2f\n", pe.kind, pe.tile, q.N, q.Cx,
                     q.H, q.W, q.Cy, q.OH, q.OW, q.KH, q.KW, q.SH, q.SW, pe.gx, pe.gy, pe.gz, ms * 1e3, pe.flops * 1e-9,
@@ -1901,6 +1901,11 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
     static char buf[5][7][48];
+    static char nbuf[3][7][48];
+    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 3 && tile >= 0 && tile < 4) {
+        snprintf(nbuf[kind - MGVAE_PROF_NHWC_FWD][tile], 48, "nhwc_igemm_kernel<%d, %s>", kind - MGVAE_PROF_NHWC_FWD, tiles[tile]);
+        return nbuf[kind - MGVAE_PROF_NHWC_FWD][tile];
+    }
     if (kind == MGVAE_PROF_ADAM) return "adam_kernel";
     if (kind == MGVAE_PROF_INORM_FWD) return "instance_norm_fwd_*";
     if (kind == MGVAE_PROF_INORM_BWD) return "instance_norm_bwd_*";
@@ -1936,3 +1941,5 @@ extern "C" const char* mgvae_strerror(int code) {
         default: return "unknown error";
     }
 }
+
+#include "conv_nhwc.inc"

@@ -46,6 +46,9 @@ SIGNATURES = {
     "mgvae_conv2d_fwd_masked": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_bwd_data_masked": (c_int, [ctypes.POINTER(ConvDesc), P, P, c_int, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
+    "mgvae_conv2d_nhwc_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),
     "mgvae_conv2d_fwd_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),

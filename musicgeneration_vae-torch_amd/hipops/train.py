@@ -184,8 +184,9 @@ class GraphedPretrainStep:
         opt = self.step_obj.opt
         b1, b2 = opt.betas
         h = opt._hyper_host
-        h[0] = opt.param_groups[0]["lr"] / (1.0 - b1 ** opt.step_count)
-        h[1] = math.sqrt(1.0 - b2 ** opt.step_count)
+        t = max(1, opt.step_count)         # (0 only while the graph is being captured: nothing executes then)
+        h[0] = opt.param_groups[0]["lr"] / (1.0 - b1 ** t)
+        h[1] = math.sqrt(1.0 - b2 ** t)
         h[2], h[3] = b1, b2
 
     def _body(self):

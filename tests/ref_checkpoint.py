@@ -1,6 +1,6 @@
 """Builds a checkpoint in the REFERENCE's layout without the reference: plain torch modules whose parameter / buffer
 names and shapes come from tests/golden/manifest.json (written from the reference import by oracle/make_golden.py) plus
-the 30 Refiner entries of graph/refiner.py:11-47 (with the reference's own -- unrunnable, defect D2 -- shapes), wrapped in
+the 30 Refiner entries of graph/refiner.py:11-47 (with the reference's own -- unrunnable, defect D2 -- shapes), keyed like
 nn.DataParallel (``module.`` prefixes) and optimised by torch.optim.Adam, i.e. exactly what
 agent/barGen2.py:168-177 hands to torch.save.  Used by tests/test_checkpoint_gpu.py; run as a script to write one:
 
@@ -71,9 +71,18 @@ def generator_entries(man):
            [["phrase_encoder." + n, s] for n, s in man["phrase_encoder"]]
 
 
+class DataParallelKeys(nn.Module):
+    """what nn.DataParallel does to a state_dict -- every key gains the ``module.`` prefix -- without its side effect on
+    a one-GPU box (it moves the wrapped module to that GPU; the fixture is built on the host)"""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
 def trained(module, rng, lr, steps=2):
-    """DataParallel wrapper + torch.optim.Adam after ``steps`` steps on random gradients"""
-    dp = nn.DataParallel(module)
+    """DataParallel-style wrapper + torch.optim.Adam after ``steps`` steps on random gradients"""
+    dp = DataParallelKeys(module)
     opt = torch.optim.Adam(dp.parameters(), lr=lr)
     for _ in range(steps):
         for p in dp.parameters():

@@ -80,7 +80,7 @@ def test_reference_layout_checkpoint_round_trip(tmp_path):
     assert steps > 3
     # (4) the saved file loads into plain torch modules + torch.optim.Adam (refiner-less generator: 221 entries)
     man = RC.manifest()
-    dp2 = torch.nn.DataParallel(RC.bag(RC.generator_entries(man), np.random.default_rng(9)))
+    dp2 = RC.DataParallelKeys(RC.bag(RC.generator_entries(man), np.random.default_rng(9)))
     dp2.load_state_dict(ck2["generator_state_dict"])            # strict
     topt2 = torch.optim.Adam(dp2.parameters(), lr=1.0)
     topt2.load_state_dict(ck2["generator_optimizer"])

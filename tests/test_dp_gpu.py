@@ -22,7 +22,10 @@ def _run(port, *args, env_extra=None, timeout=600):
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_check.py")] + list(args)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     out = r.stdout + r.stderr
-    assert "DPCHECK PASS" in out, out[-3000:]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dp_check_%d.log" % port), "w") as f:
+        f.write(out)
+    assert "DPCHECK PASS" in out, "\n".join(l for l in out.splitlines() if "Error" in l or "error" in l or "DPCHECK" in l)[-3000:]
     return out
 
 
