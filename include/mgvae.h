@@ -194,6 +194,31 @@ int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, const float*
                    int mode, int act, float slope, int parts, void* stream);
 
 /* ---- pointwise / small ops ---------------------------------------------------------*/
+/* ---- channels-last fused InstanceNorm2d -> CBAM -> (+residual) -> activation (graph/encodingBlock.py:48-55,93-100,
+ * 110-126 on tensors stored [N, H, W, C]): x [N, P, C] dense (a conv output), res / y / dy channel slices (ctot, coff) of
+ * channels-last buffers, dres / dx dense.  C in {64, 128, 256, 512, 1024}.  u = gamma * xhat + beta is recomputed from x
+ * in every pass instead of being stored (csrc/norm_cbam_nhwc.inc).  `save` / `scratch`: workspaces of the sizes the two
+ * functions below return (floats, 16-byte aligned).  Weight-like gradients accumulate.                                   */
+size_t mgvae_norm_cbam_nhwc_save_floats(int N, int C, int H, int W);
+size_t mgvae_norm_cbam_nhwc_scratch_floats(int N, int C, int H, int W);
+int mgvae_norm_cbam_nhwc_fwd(const float* x, const float* gamma, const float* beta, const float* res, int res_ctot,
+                             int res_coff, const float* w1, const float* w2, const float* wsp, float* y, float* save,
+                             int N, int C, int H, int W, int y_ctot, int y_coff, float eps, int mode, int act,
+                             float slope, void* stream);
+int mgvae_norm_cbam_nhwc_bwd(const float* x, const float* gamma, const float* beta, const float* y, const float* dy,
+                             const float* w1, const float* w2, const float* wsp, const float* save, float* dx,
+                             float* dres, float* dgamma, float* dbeta, float* dw1, float* dw2, float* dwsp,
+                             float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff, int mode, int act,
+                             float slope, void* stream);
+/* layout changes at the ends of a channels-last island (channel slices on both sides) and the whole-map average of a
+ * channels-last tensor [N, P, C] -> [N, C] (graph/encoder.py:35, graph/phrase_encoder.py:36) with its gradient */
+int mgvae_layout_nchw_to_nhwc(const float* src, float* dst, int N, int C, int P, int src_ctot, int src_coff,
+                              int dst_ctot, int dst_coff, void* stream);
+int mgvae_layout_nhwc_to_nchw(const float* src, float* dst, int N, int C, int P, int src_ctot, int src_coff,
+                              int dst_ctot, int dst_coff, void* stream);
+int mgvae_mean_nhwc_fwd(const float* x, float* out, int N, int C, int P, void* stream);
+int mgvae_mean_nhwc_bwd(const float* dout, float* dx, int N, int C, int P, void* stream);
+
 /* dx = dy * act'(y) given the activation OUTPUT y (ReLU/LeakyReLU/Sigmoid); all three
  * tensors may be channel slices of [N, ctot, P] buffers                               */
 int mgvae_act_bwd(const float* y, const float* dy, float* dx, int N, int C, int P,

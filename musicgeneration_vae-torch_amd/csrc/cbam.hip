@@ -630,3 +630,5 @@ extern "C" int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, c
     MGVAE_CHECK_LAUNCH();
     return MGVAE_OK;
 }
+
+#include "norm_cbam_nhwc.inc"

@@ -47,9 +47,12 @@ class CBAM(nn.Module):
         ca, sa = self.channel_attention, self.spatial_attention
         return HF.cbam(u, ca.conv1.weight, ca.conv2.weight, sa.conv.weight, mode, res, act, slope, out)
 
-    def fused_norm(self, x, norm, mode, res=None, act=HF.ACT_NONE, slope=0.01, out=None):
+    def fused_norm(self, x, norm, mode, res=None, act=HF.ACT_NONE, slope=0.01, out=None, channels_last=False):
         """fused(norm(x), ...) as one node: the InstanceNorm kernel also does the channel pooling"""
         ca, sa = self.channel_attention, self.spatial_attention
+        if channels_last:
+            return HF.norm_cbam_cl(x, norm.weight, norm.bias, ca.conv1.weight, ca.conv2.weight, sa.conv.weight, norm.eps, mode,
+                                   res, act, slope, out)
         return HF.norm_cbam(x, norm.weight, norm.bias, ca.conv1.weight, ca.conv2.weight, sa.conv.weight, norm.eps, mode,
                             res, act, slope, out)
 

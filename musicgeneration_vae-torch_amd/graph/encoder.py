@@ -1,4 +1,6 @@
 """Bar encoder on HIP kernels (reference: graph/encoder.py:7-40)."""
+import os
+
 import torch
 from torch import nn
 
@@ -13,14 +15,18 @@ class _ConvTrunk(nn.Module):
     pool_hw = (3, 2)
     linear_bias = True
 
-    def __init__(self, layers, variational=False):
+    def __init__(self, layers, variational=False, channels_last=None):
         super().__init__()
         self.variational = bool(variational)
+        # the residual / pooling trunk (78 % of the encoder's MACs) runs on channels-last tensors: K-contiguous conv
+        # operands (csrc/conv_nhwc.inc) and the pixel-row InstanceNorm / CBAM kernels (csrc/norm_cbam_nhwc.inc).  The two
+        # stems (C = 1 inputs) stay NCHW; their concatenated output is converted once.  MGVAE_LAYOUT=nchw switches back.
+        self.channels_last = (os.environ.get("MGVAE_LAYOUT", "nhwc") != "nchw") if channels_last is None else bool(channels_last)
         self.time_pitch = TimePitchModule()
         self.pitch_time = PitchTimeModule()
         blocks = []
         for cin, cout in zip(layers[:-1], layers[1:]):
-            blocks += [ResidualModule(cin), PoolingModule(cin, cout)]
+            blocks += [ResidualModule(cin, self.channels_last), PoolingModule(cin, cout, self.channels_last)]
         self.layers = nn.ModuleList(blocks)
         self.linear = Linear(1024, 1152, bias=self.linear_bias)
         if self.variational:
@@ -38,6 +44,8 @@ class _ConvTrunk(nn.Module):
         pitch = self.pitch_time(x, out=cat[:, :32])
         time = self.time_pitch(x, out=cat[:, 32:])
         o = HF.join(cat, pitch, time)
+        if self.channels_last:
+            o = HF.to_channels_last(o)
         # when the gradient of this tensor exists, every parameter gradient of ``layers`` and ``linear`` is enqueued:
         # the data-parallel step hooks it to start that range's all-reduce early (hipops/train.py)
         self.trunk_input = o if o.requires_grad else None
@@ -45,7 +53,7 @@ class _ConvTrunk(nn.Module):
             o = blk(o)
         if tuple(o.shape[2:]) != self.pool_hw:
             raise RuntimeError("AvgPool2d%s expects a %s map, got %s" % (self.pool_hw, self.pool_hw, tuple(o.shape[2:])))
-        return HF.global_avg_pool(o)
+        return HF.global_avg_pool_cl(o) if self.channels_last else HF.global_avg_pool(o)
 
     def forward(self, x):
         feat = self.features(x)

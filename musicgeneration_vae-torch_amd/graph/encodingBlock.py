@@ -46,10 +46,11 @@ class PitchTimeModule(_Stem):
 class ResidualModule(nn.Module):
     """graph/encodingBlock.py:70-100: relu(x + CBAM(IN(conv2(relu(conv1(x))))))"""
 
-    def __init__(self, channel):
+    def __init__(self, channel, channels_last=False):
         super().__init__()
-        self.conv1 = Conv2d(channel, channel, 3, stride=1, padding=1, bias=False)
-        self.conv2 = Conv2d(channel, channel, 3, stride=1, padding=1, bias=False)
+        self.channels_last = bool(channels_last)
+        self.conv1 = Conv2d(channel, channel, 3, stride=1, padding=1, bias=False, channels_last=channels_last)
+        self.conv2 = Conv2d(channel, channel, 3, stride=1, padding=1, bias=False, channels_last=channels_last)
         self.bn = InstanceNorm2d(channel, eps=1e-5, momentum=0.01, affine=True)
         self.cbam = CBAM(channel)
         self.apply(weights_init)
@@ -57,18 +58,19 @@ class ResidualModule(nn.Module):
     def forward(self, x, out=None):
         # conv1's ReLU gradient is applied by conv2's data gradient (conv2 is the only consumer of relu(conv1(x)))
         o = self.conv2(self.conv1(x, act=HF.ACT_RELU, defer_act_grad=True), in_act=(HF.ACT_RELU, 0.0))
-        return self.cbam.fused_norm(o, self.bn, 2, res=x, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(o, self.bn, 2, res=x, act=HF.ACT_RELU, out=out, channels_last=self.channels_last)
 
 
 class PoolingModule(nn.Module):
     """graph/encodingBlock.py:103-126: relu(u + CBAM(u)), u = IN(conv3x3 s2 (x))"""
 
-    def __init__(self, in_channel, out_channel):
+    def __init__(self, in_channel, out_channel, channels_last=False):
         super().__init__()
-        self.conv = Conv2d(in_channel, out_channel, 3, stride=2, padding=1, bias=False)
+        self.channels_last = bool(channels_last)
+        self.conv = Conv2d(in_channel, out_channel, 3, stride=2, padding=1, bias=False, channels_last=channels_last)
         self.bn = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
         self.cbam = CBAM(out_channel)
         self.apply(weights_init)
 
     def forward(self, x, out=None):
-        return self.cbam.fused_norm(self.conv(x), self.bn, 1, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(self.conv(x), self.bn, 1, act=HF.ACT_RELU, out=out, channels_last=self.channels_last)

@@ -24,15 +24,24 @@ def _default_init(weight, bias, fan_in):
 
 
 class Conv2d(nn.Module):
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+    """``channels_last=True``: the layer works on channels-last activations and keeps its weight STORED [Cout, KH, KW, Cin]
+    (torch.channels_last: same logical shape, same state_dict entry) -- the K-contiguous operand of csrc/conv_nhwc.inc."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, channels_last=False):
         super().__init__()
         self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
-        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.channels_last = bool(channels_last)
+        w = torch.empty(out_channels, in_channels, *self.kernel_size)
+        if self.channels_last:
+            w = torch.empty(out_channels, *self.kernel_size, in_channels).permute(0, 3, 1, 2)
+        self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         _default_init(self.weight, self.bias, in_channels * self.kernel_size[0] * self.kernel_size[1])
 
     def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None, in_act=None, defer_act_grad=False):
         """in_act / defer_act_grad: see hipops.functional._ConvFn (activation gradient folded into the consumer)"""
+        if self.channels_last:
+            return HF.conv2d_cl(x, self.weight, self.bias, self.stride, self.padding, act, slope, out, in_act, defer_act_grad)
         return HF.conv2d(x, self.weight, self.bias, self.stride, self.padding, act, slope, out, in_act, defer_act_grad)
 
 

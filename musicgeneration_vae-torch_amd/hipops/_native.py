@@ -64,6 +64,14 @@ SIGNATURES = {
     "mgvae_cbam_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     "mgvae_cbam_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_cbam_bwd": (c_int, [P] * 13 + [c_int] * 8 + [c_float, c_int, P]),
+    "mgvae_norm_cbam_nhwc_save_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mgvae_norm_cbam_nhwc_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mgvae_norm_cbam_nhwc_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_int, c_float, P]),
+    "mgvae_norm_cbam_nhwc_bwd": (c_int, [P] * 17 + [c_int] * 8 + [c_float, P]),
+    "mgvae_layout_nchw_to_nhwc": (c_int, [P, P] + [c_int] * 7 + [P]),
+    "mgvae_layout_nhwc_to_nchw": (c_int, [P, P] + [c_int] * 7 + [P]),
+    "mgvae_mean_nhwc_fwd": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "mgvae_mean_nhwc_bwd": (c_int, [P, P, c_int, c_int, c_int, P]),
     "mgvae_act_bwd": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
     "mgvae_copy2d": (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     "mgvae_add_inplace": (c_int, [P, P, c_size_t, P]),

@@ -41,10 +41,12 @@ class FlatParams:
         self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
-                n = p.numel()
-                self.flat[o:o + n].copy_(p.detach().reshape(-1))
-                p.data = self.flat[o:o + n].view(p.shape)
-                g = self.grad[o:o + n].view(p.shape)
+                # the parameter keeps its own (dense) memory order inside the flat buffer: a channels-last conv weight
+                # stays stored [Cy, KH, KW, Cx] -- Adam and the gradient exchange are elementwise, only the kernels care
+                v = self._view(self.flat, p, o)
+                v.copy_(p.detach())
+                p.data = v
+                g = self._view(self.grad, p, o)
                 p._mg_grad = g
                 p.grad = g
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -55,6 +57,20 @@ class FlatParams:
         self._hyper_host = self._hyper_ring[0]      # the row a captured graph re-reads (GraphedPretrainStep)
         self._hyper = torch.zeros(4, device=dev, dtype=torch.float32)
         self.param_groups = [{"lr": lr, "params": self.params}]   # ReduceLROnPlateau-compatible surface
+
+    @staticmethod
+    def _view(buf, p, o):
+        """the slice of ``buf`` that parameter ``p`` (offset ``o``) occupies, with p's shape AND memory order"""
+        st = p.stride()
+        dense = sorted(zip(st, p.shape), reverse=True)
+        span, ok = 1, True
+        for s_, n_ in reversed(dense):
+            if n_ > 1 and s_ != span:
+                ok = False
+            span *= n_
+        if not ok:          # not a dense permutation (never the case for module parameters): fall back to row-major
+            return buf[o:o + p.numel()].view(p.shape)
+        return torch.as_strided(buf, p.shape, st, o)
 
     # ---- torch.optim.Optimizer-like surface used by the agents -------------------------
     def zero_grad(self):
@@ -96,8 +112,8 @@ class FlatParams:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
                 state[i] = {"step": torch.tensor(float(self.step_count)),
-                            "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
-                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+                            "exp_avg": self._view(self.exp_avg, p, o).clone(),
+                            "exp_avg_sq": self._view(self.exp_avg_sq, p, o).clone()}
         group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
                  "amsgrad": False, "params": list(range(len(self.params)))}
         return {"state": state, "param_groups": [group]}
@@ -114,8 +130,8 @@ class FlatParams:
                 continue                      # e.g. refiner parameters of a reference checkpoint
             p, o = self.params[i], self.offsets[i]
             n = p.numel()
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self._view(self.exp_avg, p, o).copy_(st["exp_avg"])
+            self._view(self.exp_avg_sq, p, o).copy_(st["exp_avg_sq"])
             steps.append(int(float(st["step"])))
         self.step_count = max(steps) if steps else 0
 

@@ -1070,3 +1070,260 @@ def reparam_kl(mean, logvar, eps=None):
     if eps is None:
         eps = randn(tuple(mean.shape), 1.0, mean.device)
     return _ReparamKlFn.apply(mean, logvar, eps)
+
+
+# ====================================================================== channels-last (NHWC) family
+# Activations stored [N, H, W, C] and conv weights stored [Cy, KH, KW, Cx] -- torch.channels_last for both, so logical
+# shapes, state_dict entries and everything that indexes tensors logically (tests, checkpoints) are unchanged.  The GEMM's
+# K axis (tap, channel) is then contiguous in memory: csrc/conv_nhwc.inc.  The encoder trunks run in this layout
+# (graph/encoder.py); ``to_channels_last`` / ``to_nchw`` convert at the ends of such an island.
+CL = torch.channels_last
+
+
+def cl_pitch(t):
+    """channel pitch (floats between consecutive pixels) of an NCHW-shaped tensor whose memory is channels-last --
+    dense, or a channel slice of a wider channels-last buffer; None for any other layout"""
+    n, c, h, w = t.shape
+    st = t.stride()
+    if c > 1 and st[1] != 1:
+        return None
+    if w > 1:
+        ct = st[3]
+    elif h > 1:
+        ct = st[2]
+    elif n > 1:
+        ct = st[0]
+    else:
+        ct = c
+    if ct < c or (h > 1 and st[2] != w * ct) or (n > 1 and st[0] != h * w * ct):
+        return None
+    return ct
+
+
+def new_channels_last(n, c, h, w, device):
+    return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def _need_cl(t, what):
+    _need_cuda(t, what)
+    ct = cl_pitch(t)
+    if ct is None or (ct % 4) or (t.data_ptr() % 16):
+        raise RuntimeError("%s: expected a channels-last tensor (stride %s of shape %s is not)" % (what, t.stride(), tuple(t.shape)))
+    return ct
+
+
+def _cl_weight(w, what):
+    co, ci, kh, kw = w.shape
+    if w.stride() != (kh * kw * ci, 1, kw * ci, ci) and not (kh == 1 and kw == 1 and w.stride(0) == ci and w.stride(1) == 1):
+        raise RuntimeError("%s: the channels-last kernels need the weight stored [Cy, KH, KW, Cx] (torch.channels_last): build "
+                           "the layer with channels_last=True" % what)
+
+
+def _cl_mask(t, act, slope):
+    ct = _need_cl(t, "activation mask")
+    return nat.ActMask(t.data_ptr(), ct, 0, act, slope), t
+
+
+class _ToChannelsLastFn(torch.autograd.Function):
+    """NCHW (dense or a channel slice) -> dense channels-last copy; backward converts the gradient back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "to_channels_last")
+        x, xct = _sliceable(x)
+        N, C, H, W = x.shape
+        y = new_channels_last(N, C, H, W, x.device)
+        nat.check(nat.lib().mgvae_layout_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, xct, 0, C, 0, _s()), "nchw_to_nhwc")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ct = _need_cl(dy, "to_channels_last backward")
+        N, C, H, W = dy.shape
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_layout_nhwc_to_nchw(_p(dy), _p(dx), N, C, H * W, ct, 0, C, 0, _s()), "nhwc_to_nchw")
+        return dx
+
+
+class _ToNchwFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ct = _need_cl(x, "to_nchw")
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_layout_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, ct, 0, C, 0, _s()), "nhwc_to_nchw")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy, dct = _sliceable(dy)
+        N, C, H, W = dy.shape
+        dx = new_channels_last(N, C, H, W, dy.device)
+        nat.check(nat.lib().mgvae_layout_nchw_to_nhwc(_p(dy), _p(dx), N, C, H * W, dct, 0, C, 0, _s()), "nchw_to_nhwc")
+        return dx
+
+
+def to_channels_last(x):
+    return _ToChannelsLastFn.apply(x)
+
+
+def to_nchw(x):
+    return _ToNchwFn.apply(x)
+
+
+class _ConvClFn(torch.autograd.Function):
+    """nn.Conv2d on channels-last tensors (graph/encodingBlock.py:74-77,107-108): forward, data gradient (stride
+    phases) and weight gradient of csrc/conv_nhwc.inc; the weight is stored [Cy, KH, KW, Cx] and its gradient is
+    accumulated in that same layout."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act, slope, out, in_act=None, defer_act_grad=False):
+        xct = _need_cl(x, "conv2d (channels-last)")
+        _cl_weight(w, "conv2d (channels-last)")
+        N, Cx, H, W = x.shape
+        Cy, _, KH, KW = w.shape
+        OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+        OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        y = out if out is not None else new_channels_last(N, Cy, OH, OW, x.device)
+        yct = _need_cl(y, "conv2d (channels-last) output")
+        d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
+        nat.check(nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "conv2d_nhwc_fwd")
+        ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
+        if not DEFER_ACT_GRAD:
+            in_act, defer_act_grad = None, False
+        ctx.in_act, ctx.defer = in_act, bool(defer_act_grad)          # see _ConvFn.forward
+        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer_act_grad) else None)
+        ctx.b = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, Cx, H, W, Cy, OH, OW, k, s, p, xct, act, slope = ctx.geom
+        L = nat.lib()
+        if _trunk_streams or _used_sides:
+            _ensure_join_callback()
+        if cl_pitch(dy) is None:
+            dy = dy.contiguous(memory_format=CL)
+        if act != ACT_NONE and not ctx.defer:
+            dy = _act_bwd_cl(y, dy, act, slope)
+        dct = _need_cl(dy, "conv2d (channels-last) backward")
+        d = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, xct, dct, ACT_NONE, 0.0)
+        b = ctx.b
+
+        def weight_grads():
+            if w.requires_grad:
+                nat.check(L.mgvae_conv2d_nhwc_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_nhwc_bwd_weight")
+            if b is not None and b.requires_grad:
+                raise RuntimeError("channels-last conv: bias gradient not implemented (the trunk convs have no bias)")
+
+        if FORK_WGRAD and N >= FORK_MIN_BATCH and ctx.needs_input_grad[0] and w.requires_grad:
+            _wgrad_rr[0] += 1
+            with _forked(x, dy, slot=2 + _wgrad_rr[0] % WGRAD_STREAMS):
+                weight_grads()
+        else:
+            weight_grads()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_channels_last(N, Cx, H, W, dy.device)
+            d2 = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, Cx, dct, ACT_NONE, 0.0)
+            m = None
+            if ctx.in_act:
+                m, keep = _cl_mask(x, *ctx.in_act)
+            nat.check(L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), ctypes.byref(m) if m is not None else None,
+                                                   _s()), "conv2d_nhwc_bwd_data")
+        return dx, None, None, None, None, None, None, None, None, None
+
+
+def _act_bwd_cl(y, dy, act, slope):
+    """dx = dy * act'(y) for channels-last tensors (dense result).  Elementwise over pixel rows: the NCHW kernel with the
+    roles of the axes swapped (rows of C channels at a pitch)"""
+    yct = _need_cl(y, "act_bwd"); dct = _need_cl(dy, "act_bwd")
+    n, c, h, w = y.shape
+    dx = new_channels_last(n, c, h, w, y.device)
+    # [N*H*W rows, C] with row pitches: mgvae_act_bwd addresses [N', C', P'] tensors as ((n * ctot + coff + c) * P + p);
+    # with N' = rows, C' = 1... the pitch must be per row: use P' = 1 and ctot = pitch
+    rows = n * h * w
+    nat.check(nat.lib().mgvae_act_bwd(_p(y), _p(dy), _p(dx), rows, c, 1, yct, 0, dct, 0, c, 0, act, slope, _s()), "act_bwd")
+    return dx
+
+
+def conv2d_cl(x, w, b=None, stride=(1, 1), pad=(0, 0), act=ACT_NONE, slope=0.01, out=None, in_act=None, defer_act_grad=False):
+    return _ConvClFn.apply(x, w, b, stride, pad, act, slope, out, in_act, defer_act_grad)
+
+
+class _NormCbamClFn(torch.autograd.Function):
+    """InstanceNorm2d -> CBAM -> (+residual) -> activation on channels-last tensors as ONE node
+    (graph/encodingBlock.py:48-55,93-100,110-126): csrc/norm_cbam_nhwc.inc"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, w1, w2, wsp, eps, mode, act, slope, out):
+        xct = _need_cl(x, "norm_cbam (channels-last)")
+        N, C, H, W = x.shape
+        if xct != C:
+            raise RuntimeError("norm_cbam (channels-last): the normalised tensor must be dense")
+        rct = 0
+        if res is not None:
+            rct = _need_cl(res, "norm_cbam residual")
+        L = nat.lib()
+        y = out if out is not None else new_channels_last(N, C, H, W, x.device)
+        yct = _need_cl(y, "norm_cbam output")
+        save = torch.empty((L.mgvae_norm_cbam_nhwc_save_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
+        nat.check(L.mgvae_norm_cbam_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(res), rct, 0, _p(w1), _p(w2), _p(wsp), _p(y), _p(save),
+                                             N, C, H, W, yct, 0, eps, mode, act, slope, _s()), "norm_cbam_nhwc_fwd")
+        ctx.save_for_backward(x, gamma, beta, y, w1, w2, wsp, save)
+        ctx.cfg = (mode, act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, y, w1, w2, wsp, save = ctx.saved_tensors
+        mode, act, slope = ctx.cfg
+        N, C, H, W = x.shape
+        L = nat.lib()
+        yct = cl_pitch(y)
+        if cl_pitch(dy) != yct:          # the kernels address y and dy with one pitch
+            y = y.contiguous(memory_format=CL); dy = dy.contiguous(memory_format=CL); yct = C
+        dx = new_channels_last(N, C, H, W, x.device)
+        dres = new_channels_last(N, C, H, W, x.device) if mode == 2 else None
+        scratch = torch.empty((L.mgvae_norm_cbam_nhwc_scratch_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
+        dg = grad_slot(gamma) if gamma.requires_grad else None
+        db = grad_slot(beta) if beta.requires_grad else None
+        dw1 = grad_slot(w1) if w1.requires_grad else None
+        dw2 = grad_slot(w2) if w2.requires_grad else None
+        dws = grad_slot(wsp) if wsp.requires_grad else None
+        nat.check(L.mgvae_norm_cbam_nhwc_bwd(_p(x), _p(gamma), _p(beta), _p(y), _p(dy), _p(w1), _p(w2), _p(wsp), _p(save), _p(dx),
+                                             _p(dres), _p(dg), _p(db), _p(dw1), _p(dw2), _p(dws), _p(scratch), N, C, H, W, yct, 0,
+                                             mode, act, slope, _s()), "norm_cbam_nhwc_bwd")
+        return (dx, None, None, dres) + (None,) * 8
+
+
+def norm_cbam_cl(x, gamma, beta, w1, w2, wsp, eps=1e-5, mode=0, res=None, act=ACT_NONE, slope=0.01, out=None):
+    return _NormCbamClFn.apply(x, gamma, beta, res, w1, w2, wsp, eps, mode, act, slope, out)
+
+
+class _MeanClFn(torch.autograd.Function):
+    """whole-map average of a channels-last tensor (graph/encoder.py:20,35)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ct = _need_cl(x, "global_avg_pool (channels-last)")
+        N, C, H, W = x.shape
+        if ct != C:
+            raise RuntimeError("global_avg_pool (channels-last): dense input expected")
+        out = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_mean_nhwc_fwd(_p(x), _p(out), N, C, H * W, _s()), "mean_nhwc_fwd")
+        ctx.shape = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, C, H, W = ctx.shape
+        dout = dout.contiguous()
+        dx = new_channels_last(N, C, H, W, dout.device)
+        nat.check(nat.lib().mgvae_mean_nhwc_bwd(_p(dout), _p(dx), N, C, H * W, _s()), "mean_nhwc_bwd")
+        return dx
+
+
+def global_avg_pool_cl(x):
+    return _MeanClFn.apply(x)

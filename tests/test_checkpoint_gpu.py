@@ -48,9 +48,8 @@ def test_reference_layout_checkpoint_round_trip(tmp_path):
     tparams = [p for p in dp.parameters()]
     for i, (p, o) in enumerate(zip(opt.params, opt.offsets)):
         st = topt.state[tparams[i]]
-        n = p.numel()
-        assert torch.equal(opt.exp_avg[o:o + n].cpu(), st["exp_avg"].reshape(-1)), i
-        assert torch.equal(opt.exp_avg_sq[o:o + n].cpu(), st["exp_avg_sq"].reshape(-1)), i
+        assert torch.equal(opt._view(opt.exp_avg, p, o).cpu(), st["exp_avg"]), i          # (logical comparison: a
+        assert torch.equal(opt._view(opt.exp_avg_sq, p, o).cpu(), st["exp_avg_sq"]), i    # channels-last weight is permuted)
     assert opt.step_count == 2 and abs(opt.param_groups[0]["lr"] - 0.0016) < 1e-12
     assert agent.opt_Zdiscriminator_bar.step_count == 2
     # (2) the next Adam step continues torch's: same gradient into both, third step's bias corrections
@@ -86,8 +85,8 @@ def test_reference_layout_checkpoint_round_trip(tmp_path):
     topt2.load_state_dict(ck2["generator_optimizer"])
     p0 = next(iter(dp2.parameters()))
     assert int(topt2.state[p0]["step"]) == steps and abs(topt2.param_groups[0]["lr"] - agent.get_lr(agent.opt_generator)) < 1e-12
-    o0 = agent.opt_generator.offsets[0]
-    assert torch.equal(topt2.state[p0]["exp_avg"].reshape(-1), agent.opt_generator.exp_avg[o0:o0 + p0.numel()].cpu())
+    g0 = agent.opt_generator
+    assert torch.equal(topt2.state[p0]["exp_avg"], g0._view(g0.exp_avg, g0.params[0], g0.offsets[0]).cpu())
     for p in dp2.parameters():
         p.grad = torch.zeros_like(p)
     topt2.step()                                                 # usable, not only loadable

@@ -126,3 +126,109 @@ def test_nhwc_rejects_unsupported_channel_counts():
     d = nat.ConvDesc(1, 17, 8, 8, 16, 8, 8, 3, 3, 1, 1, 1, 1, 17, 0, 16, 0, 0, 0.0)
     t = torch.zeros(8, device=dev)
     assert nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), vp(t), vp(t), None, vp(t), None, stream()) == -1
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 48, 30), (2, 128, 24, 15), (2, 256, 12, 8), (3, 512, 6, 4), (2, 1024, 3, 2), (2, 64, 192, 30)])
+@pytest.mark.parametrize("mode,act", [(1, 1), (2, 1), (1, 2), (0, 0)])
+def test_norm_cbam_channels_last(shape, mode, act):
+    """InstanceNorm -> CBAM -> (+residual) -> activation on channels-last tensors (u never materialised, channel
+    pooling from the statistics pass) against the fp64 oracle: forward, dx, dres, affine and all CBAM weight gradients;
+    output written into a channel slice of a wider channels-last buffer; negative and zero gammas included (max_hw(u)
+    then sits at the minimum of x / at pixel 0)"""
+    from hipops import functional as HF
+    from oracle import restate as R
+    N, C, H, W_ = shape
+    x = torch.randn(shape) * 2 + 0.5; res = torch.randn(shape)
+    g = torch.randn(C); b = torch.randn(C)
+    g[3] = 0.0; g[5] = -abs(g[5]) - 0.1
+    sd = {"channel_attention.conv1.weight": torch.randn(C // 16, C, 1, 1) * 0.2,
+          "channel_attention.conv2.weight": torch.randn(C, C // 16, 1, 1) * 0.2,
+          "spatial_attention.conv.weight": torch.randn(1, 2, 3, 3) * 0.3}
+    sdr = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    fn = (lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.01))[act]
+    ur = F.instance_norm(xr, None, None, gr, br, True, 0.01, 1e-5)
+    o = R.cbam(sdr, "", ur)
+    yr = o if mode == 0 else (fn(ur + o) if mode == 1 else fn(rr + o))
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xd = cl(x).requires_grad_(True); rd = cl(res).requires_grad_(True)
+    gd = torch.nn.Parameter(g.to(dev)); bd = torch.nn.Parameter(b.to(dev))
+    ps = {k: torch.nn.Parameter(v.to(dev)) for k, v in sd.items()}
+    buf = cl(torch.full((N, C + 32, H, W_), 7.0))
+    y = HF.norm_cbam_cl(xd, gd, bd, ps["channel_attention.conv1.weight"], ps["channel_attention.conv2.weight"],
+                        ps["spatial_attention.conv.weight"], 1e-5, mode, rd if mode == 2 else None, act, 0.01, out=buf[:, 16:16 + C])
+    tag = "norm_cbam_cl %s mode%d act%d" % (shape, mode, act)
+    check(tag + " fwd", y, yr)
+    assert float(buf[:, :16].min()) == 7.0 and float(buf[:, 16 + C:].max()) == 7.0          # neighbours untouched
+    y.backward(cl(dy.float()))
+    check(tag + " dx", xd.grad, xr.grad)
+    check(tag + " dgamma", gd.grad, gr.grad); check(tag + " dbeta", bd.grad, br.grad)
+    if mode == 2:
+        check(tag + " dres", rd.grad, rr.grad)
+    for k in sd:
+        check(tag + " d" + k, ps[k].grad, sdr[k].grad)
+
+
+def test_layout_round_trip_and_mean():
+    from hipops import functional as HF
+    x = torch.randn(3, 70, 9, 7)
+    big = torch.randn(3, 100, 9, 7).to(dev)
+    big[:, 10:80] = x.to(dev)
+    xs = big[:, 10:80].detach().requires_grad_(True)                # an NCHW channel slice
+    y = HF.to_channels_last(xs)
+    assert HF.cl_pitch(y) == 70 and torch.equal(y.cpu(), x)
+    z = HF.to_nchw(y)
+    assert z.is_contiguous() and torch.equal(z.cpu(), x)
+    w = torch.randn(3, 70, 9, 7)
+    (z * w.to(dev)).sum().backward()
+    assert torch.equal(xs.grad.cpu(), w)
+    t = cl(torch.randn(4, 1024, 3, 2)).requires_grad_(True)
+    m = HF.global_avg_pool_cl(t)
+    check("mean_nhwc fwd", m, t.detach().double().cpu().mean(dim=(2, 3)))
+    dm = torch.randn(4, 1024)
+    m.backward(dm.to(dev))
+    check("mean_nhwc bwd", t.grad, (dm.double() / 6).view(4, 1024, 1, 1).expand(4, 1024, 3, 2))
+
+
+@pytest.mark.parametrize("mode", ["wc", "d4"])
+def test_channels_last_blocks_against_oracle(mode):
+    """the encoder trunk's two block types on the channels-last kernels (conv -> [ReLU -> conv] -> fused norm / CBAM /
+    residual) against the fp64 oracle, with channels-last weights inside a flat parameter buffer"""
+    import graph.encodingBlock as EB
+    from hipops import FlatParams
+    from hipops import functional as HF
+    from oracle import restate as R, weights as W
+    from parity_util import check_grad, TOL
+    gsd = W.make_state_dict(W.manifest_generator(), 0, mode)
+    tol = TOL if mode == "wc" else 5e-3
+    cases = [("cl.residual64", EB.ResidualModule(64, True), "encoder.layers.0.", R.residual_module, torch.randn(3, 64, 48, 30).relu_()),
+             ("cl.pooling64", EB.PoolingModule(64, 128, True), "encoder.layers.1.", R.pooling_module, torch.randn(3, 64, 48, 30).relu_()),
+             ("cl.residual512", EB.ResidualModule(512, True), "encoder.layers.6.", R.residual_module, torch.randn(3, 512, 6, 4).relu_()),
+             ("cl.pooling512", EB.PoolingModule(512, 1024, True), "encoder.layers.7.", R.pooling_module, torch.randn(3, 512, 6, 4).relu_()),
+             ("cl.residual128 odd", EB.ResidualModule(128, True), "encoder.layers.2.", R.residual_module, torch.randn(2, 128, 24, 15).relu_())]
+    for tag, mod, prefix, ofn, x in cases:
+        sub = {k[len(prefix):]: v for k, v in gsd.items() if k.startswith(prefix)}
+        mod.load_state_dict(sub)
+        mod = mod.to(dev)
+        assert mod.state_dict()["conv1.weight" if "residual" in tag else "conv.weight"].stride(1) == 1      # stored channels-last
+        opt = FlatParams(list(mod.parameters()))
+        opt.zero_grad()
+        osd = {k: v.clone().double().requires_grad_(True) for k, v in sub.items()}
+        o32 = {k: v.clone().requires_grad_(True) for k, v in sub.items()}
+        xr = x.double().requires_grad_(True)
+        yr = ofn(osd, "", xr)
+        dy = torch.randn_like(yr)
+        yr.backward(dy)
+        x32 = x.clone().requires_grad_(True)
+        ofn(o32, "", x32).backward(dy.float())
+        xd = x.to(dev).requires_grad_(True)
+        y = mod(HF.to_channels_last(xd))
+        check("%s[%s] fwd" % (tag, mode), y, yr, tol)
+        y.backward(dy.float().to(dev))
+        check_grad("%s[%s] dx" % (tag, mode), xd.grad, xr.grad, tol, ref32=x32.grad)
+        gscale = max(v.grad.abs().max().item() for v in osd.values() if v.grad is not None)
+        for n, p in mod.named_parameters():
+            check_grad("%s[%s] d%s" % (tag, mode, n), p.grad, osd[n].grad, tol, atol=1e-6 * gscale, ref32=o32[n].grad)
+            assert p.grad.data_ptr() >= opt.grad.data_ptr()          # accumulated straight into the flat gradient
