@@ -265,12 +265,12 @@ def main():
         n = L.mgvae_prof_collect(recs, 64)
         L.mgvae_prof_enable(0)
         L.mgvae_prof_detail(b"")
-        conv = [r for r in recs[:n] if r.kind < 5]
+        conv = [r for r in recs[:n] if r.kind < 5 or r.kind >= 8]          # NCHW + channels-last conv families
         # the HBM-bound kernels (flat Adam, InstanceNorm): `flops` carries their ALGORITHMIC bytes (include/mgvae.h)
         hbm = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,
                 "avg_us": 1e3 * r.ms / r.launches, "achieved": r.flops / (r.ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": r.flops / (r.ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": r.flops / r.launches} for r in recs[:n] if r.kind >= 5]
+                "algorithmic_bytes_per_launch": r.flops / r.launches} for r in recs[:n] if 5 <= r.kind < 8]
         fam = [{"kernel": L.mgvae_kernel_name(r.kind, r.tile).decode(), "launches": r.launches, "ms": r.ms,
                 "avg_us": 1e3 * r.ms / r.launches, "tflops": r.flops / (r.ms * 1e-3) / 1e12} for r in conv]
         fam.sort(key=lambda f: -f["ms"])

@@ -210,6 +210,14 @@ int mgvae_norm_cbam_nhwc_bwd(const float* x, const float* gamma, const float* be
                              float* dres, float* dgamma, float* dbeta, float* dw1, float* dw2, float* dwsp,
                              float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff, int mode, int act,
                              float slope, void* stream);
+/* InstanceNorm2d (+ReLU / LeakyReLU) alone on channels-last tensors (graph/decoder.py:81-83,124-126); `stats`: 6 N C
+ * floats kept for backward, `scratch`: 2 N C floats; and the bias gradient of a transposed conv (sum over pixel rows).   */
+int mgvae_instance_norm_nhwc_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int N,
+                                 int C, int H, int W, int y_ctot, int y_coff, float eps, int act, float slope, void* stream);
+int mgvae_instance_norm_nhwc_bwd(const float* x, const float* gamma, const float* stats, const float* y, const float* dy,
+                                 float* dx, float* dgamma, float* dbeta, float* scratch, int N, int C, int H, int W,
+                                 int y_ctot, int y_coff, int act, float slope, void* stream);
+int mgvae_channel_sum_nhwc_accum(const float* t, long rows, int C, int ctot, int coff, float* db, void* stream);
 /* layout changes at the ends of a channels-last island (channel slices on both sides) and the whole-map average of a
  * channels-last tensor [N, P, C] -> [N, C] (graph/encoder.py:35, graph/phrase_encoder.py:36) with its gradient */
 int mgvae_layout_nchw_to_nhwc(const float* src, float* dst, int N, int C, int P, int src_ctot, int src_coff,

@@ -3,6 +3,8 @@
 Transposed convolutions run on the stride-phase data-gradient kernel (no zero taps);
 every ``torch.cat`` of the reference is a pre-allocated buffer whose channel slices the
 producers write directly."""
+import os
+
 import torch
 from torch import nn
 
@@ -10,6 +12,12 @@ from hipops import functional as HF
 from graph.cbam import CBAM
 from graph.layers import Conv2d, ConvTranspose2d, Embedding, InstanceNorm2d, Linear
 from graph.weights_initializer import weights_init
+
+
+def _new(channels_last, n, c, h, w, device):
+    if channels_last:
+        return HF.new_channels_last(n, c, h, w, device)
+    return torch.empty((n, c, h, w), device=device, dtype=torch.float32)
 
 
 class _Stem(nn.Module):
@@ -45,14 +53,15 @@ class PitchTimeModule(_Stem):
 class DeConvModule(nn.Module):
     """graph/decoder.py:69-109: ConvT4x4 s2 || ConvT3x3 s2 (+bias) -> IN -> ReLU each; cat -> 1x1 -> IN -> +CBAM -> ReLU"""
 
-    def __init__(self, in_channel, out_channel):
+    def __init__(self, in_channel, out_channel, channels_last=False):
         super().__init__()
-        self.deConv1 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, bias=False)
-        self.deConv2 = ConvTranspose2d(in_channel, out_channel, 3, stride=2, padding=1, output_padding=1, bias=True)
-        self.conv = Conv2d(in_channel, out_channel, 1, stride=1, bias=False)
-        self.bn1 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
-        self.bn2 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
-        self.bn3 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        cl = self.channels_last = bool(channels_last)
+        self.deConv1 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, bias=False, channels_last=cl)
+        self.deConv2 = ConvTranspose2d(in_channel, out_channel, 3, stride=2, padding=1, output_padding=1, bias=True, channels_last=cl)
+        self.conv = Conv2d(in_channel, out_channel, 1, stride=1, bias=False, channels_last=cl)
+        self.bn1 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True, channels_last=cl)
+        self.bn2 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True, channels_last=cl)
+        self.bn3 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True, channels_last=cl)
         self.cbam = CBAM(out_channel)
         self.out_channel = out_channel
         self.apply(weights_init)
@@ -60,26 +69,28 @@ class DeConvModule(nn.Module):
     def forward(self, x, out=None):
         co = self.out_channel
         n, _, h, w = x.shape
-        cat = torch.empty((n, 2 * co, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+        cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w, x.device)
         with HF.forked_branch(x, cat):            # the two transposed-conv branches are independent until the cat
             b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.bn1(self.deConv1(x), act=HF.ACT_RELU, out=cat[:, :co])
         HF.join_side_streams(slot=0)
-        return self.cbam.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
+        return self.cbam.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out,
+                                    channels_last=self.channels_last)
 
 
 class DeConvPitchPadding(nn.Module):
     """graph/decoder.py:112-154.  Literal about reference defect D5: ``bn2`` normalises BOTH
     branches and ``bn1`` is never used (its parameters never receive a gradient)."""
 
-    def __init__(self, in_channel, out_channel):
+    def __init__(self, in_channel, out_channel, channels_last=False):
         super().__init__()
-        self.deConv1 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, output_padding=(0, 1), bias=True)
-        self.deConv2 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, output_padding=(0, 1), bias=True)
-        self.conv = Conv2d(in_channel, out_channel, 1, stride=1, bias=False)
-        self.bn1 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
-        self.bn2 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
-        self.bn3 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True)
+        cl = self.channels_last = bool(channels_last)
+        self.deConv1 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, output_padding=(0, 1), bias=True, channels_last=cl)
+        self.deConv2 = ConvTranspose2d(in_channel, out_channel, 4, stride=2, padding=1, output_padding=(0, 1), bias=True, channels_last=cl)
+        self.conv = Conv2d(in_channel, out_channel, 1, stride=1, bias=False, channels_last=cl)
+        self.bn1 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True, channels_last=cl)
+        self.bn2 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True, channels_last=cl)
+        self.bn3 = InstanceNorm2d(out_channel, eps=1e-5, momentum=0.01, affine=True, channels_last=cl)
         self.cbam1 = CBAM(out_channel)
         self.cbam2 = CBAM(out_channel)
         self.out_channel = out_channel
@@ -88,29 +99,33 @@ class DeConvPitchPadding(nn.Module):
     def forward(self, x, out=None):
         co = self.out_channel
         n, _, h, w = x.shape
-        cat = torch.empty((n, 2 * co, 2 * h, 2 * w + 1), device=x.device, dtype=torch.float32)
+        cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w + 1, x.device)
         with HF.forked_branch(x, cat):
             b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
-        a = self.cbam1.fused_norm(self.deConv1(x), self.bn2, 1, act=HF.ACT_RELU, out=cat[:, :co])
+        a = self.cbam1.fused_norm(self.deConv1(x), self.bn2, 1, act=HF.ACT_RELU, out=cat[:, :co], channels_last=self.channels_last)
         HF.join_side_streams(slot=0)
-        return self.cbam2.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out)
+        return self.cbam2.fused_norm(self.conv(HF.join(cat, a, b)), self.bn3, 1, act=HF.ACT_RELU, out=out,
+                                     channels_last=self.channels_last)
 
 
 class Decoder(nn.Module):
     """graph/decoder.py:157-222: (z, pre_z, phrase_feature, position) -> gen [B,1,96,60] in (0,1)"""
 
-    def __init__(self, layers):
+    def __init__(self, layers, channels_last=None):
         super().__init__()
+        # fit1 and the four up-sampling blocks (94 % of the decoder's MACs) run on channels-last tensors, like the encoder
+        # trunks (graph/encoder.py); the Linear head, the two stems (1x1 maps: plain GEMMs) and fit2 (64 -> 1) stay NCHW
+        cl = self.channels_last = (os.environ.get("MGVAE_LAYOUT", "nhwc") != "nchw") if channels_last is None else bool(channels_last)
         self.bar_linear = Linear(1152 * 2, 1152)
         self.phrase_linear = Linear(1152 * 2, 1152)
         self.time = TimePitchModule()
         self.pitch = PitchTimeModule()
-        self.fit1 = Conv2d(2048, 1024, 1, stride=1, bias=False)
+        self.fit1 = Conv2d(2048, 1024, 1, stride=1, bias=False, channels_last=cl)
         self.bn = InstanceNorm2d(1024, eps=1e-5, momentum=0.01, affine=True)
         self.fit2 = Conv2d(64, 1, 1, stride=1, bias=False)
         blocks = []
         for i in range(1, len(layers)):
-            blocks.append((DeConvPitchPadding if i < 3 else DeConvModule)(layers[i - 1], layers[i]))
+            blocks.append((DeConvPitchPadding if i < 3 else DeConvModule)(layers[i - 1], layers[i], cl))
         self.layers = nn.ModuleList(blocks)
         self.cbam = CBAM(1024)
         self.position_embedding = Embedding(332, 1152)
@@ -145,7 +160,12 @@ class Decoder(nn.Module):
             time = self.time(x, out=cat[:, 1024:])
         pitch = self.pitch(x, out=cat[:, :1024])
         HF.join_side_streams(slot=0)
-        o = self.cbam.fused_norm(self.fit1(HF.join(cat, pitch, time)), self.bn, 1, act=HF.ACT_RELU)
+        o = HF.join(cat, pitch, time)
+        if self.channels_last:
+            o = HF.to_channels_last(o)
+        o = self.cbam.fused_norm(self.fit1(o), self.bn, 1, act=HF.ACT_RELU, channels_last=self.channels_last)
         for blk in self.layers:
             o = blk(o)
+        if self.channels_last:
+            o = HF.to_nchw(o)
         return self.fit2(o, act=HF.ACT_SIGMOID)

@@ -46,16 +46,23 @@ class Conv2d(nn.Module):
 
 
 class ConvTranspose2d(nn.Module):
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True,
+                 channels_last=False):
         super().__init__()
         self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
         self.padding, self.output_padding = _pair(padding), _pair(output_padding)
-        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, *self.kernel_size))
+        self.channels_last = bool(channels_last)
+        w = torch.empty(in_channels, out_channels, *self.kernel_size)
+        if self.channels_last:          # stored [Cin, KH, KW, Cout]: see Conv2d
+            w = torch.empty(in_channels, *self.kernel_size, out_channels).permute(0, 3, 1, 2)
+        self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         # torch derives fan_in of a transposed-conv weight from dim 1
         _default_init(self.weight, self.bias, out_channels * self.kernel_size[0] * self.kernel_size[1])
 
     def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None, in_act=None, defer_act_grad=False):
+        if self.channels_last:
+            return HF.conv_transpose2d_cl(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope, out)
         return HF.conv_transpose2d(x, self.weight, self.bias, self.stride, self.padding, self.output_padding, act, slope, out,
                                    in_act, defer_act_grad)
 
@@ -75,15 +82,18 @@ class InstanceNorm2d(nn.Module):
     """affine, no running statistics (the reference passes momentum=0.01, which is unused
     without running stats)"""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.01, affine=True):
+    def __init__(self, num_features, eps=1e-5, momentum=0.01, affine=True, channels_last=False):
         super().__init__()
         if not affine:
             raise ValueError("the hot path only uses affine InstanceNorm2d")
         self.eps = eps
+        self.channels_last = bool(channels_last)
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
 
     def forward(self, x, act=HF.ACT_NONE, slope=0.01, out=None):
+        if self.channels_last:
+            return HF.instance_norm_cl(x, self.weight, self.bias, self.eps, act, slope, out)
         return HF.instance_norm(x, self.weight, self.bias, self.eps, act, slope, out)
 
 

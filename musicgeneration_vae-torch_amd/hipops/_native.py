@@ -68,6 +68,9 @@ SIGNATURES = {
     "mgvae_norm_cbam_nhwc_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_norm_cbam_nhwc_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_int, c_float, P]),
     "mgvae_norm_cbam_nhwc_bwd": (c_int, [P] * 17 + [c_int] * 8 + [c_float, P]),
+    "mgvae_instance_norm_nhwc_fwd": (c_int, [P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_float, P]),
+    "mgvae_instance_norm_nhwc_bwd": (c_int, [P] * 9 + [c_int] * 7 + [c_float, P]),
+    "mgvae_channel_sum_nhwc_accum": (c_int, [P, ctypes.c_long, c_int, c_int, c_int, P, P]),
     "mgvae_layout_nchw_to_nhwc": (c_int, [P, P] + [c_int] * 7 + [P]),
     "mgvae_layout_nhwc_to_nchw": (c_int, [P, P] + [c_int] * 7 + [P]),
     "mgvae_mean_nhwc_fwd": (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -1327,3 +1327,106 @@ class _MeanClFn(torch.autograd.Function):
 
 def global_avg_pool_cl(x):
     return _MeanClFn.apply(x)
+
+
+class _InstNormClFn(torch.autograd.Function):
+    """nn.InstanceNorm2d(affine) + fused (Leaky)ReLU on channels-last tensors (graph/decoder.py:81-83,124-126)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, slope, out):
+        xct = _need_cl(x, "instance_norm (channels-last)")
+        N, C, H, W = x.shape
+        if xct != C:
+            raise RuntimeError("instance_norm (channels-last): the normalised tensor must be dense")
+        y = out if out is not None else new_channels_last(N, C, H, W, x.device)
+        yct = _need_cl(y, "instance_norm output")
+        stats = torch.empty((6 * N * C,), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_instance_norm_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), N, C, H, W, yct, 0, eps, act,
+                                                         slope, _s()), "instance_norm_nhwc_fwd")
+        ctx.save_for_backward(x, gamma, stats, y)
+        ctx.beta = beta
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats, y = ctx.saved_tensors
+        act, slope = ctx.cfg
+        N, C, H, W = x.shape
+        yct = cl_pitch(y)
+        if cl_pitch(dy) != yct:
+            y = y.contiguous(memory_format=CL); dy = dy.contiguous(memory_format=CL); yct = C
+        dx = new_channels_last(N, C, H, W, x.device)
+        scratch = torch.empty((2 * N * C,), device=x.device, dtype=torch.float32)
+        dg = grad_slot(gamma) if gamma.requires_grad else None
+        db = grad_slot(ctx.beta) if ctx.beta.requires_grad else None
+        nat.check(nat.lib().mgvae_instance_norm_nhwc_bwd(_p(x), _p(gamma), _p(stats), _p(y), _p(dy), _p(dx), _p(dg), _p(db),
+                                                         _p(scratch), N, C, H, W, yct, 0, act, slope, _s()), "instance_norm_nhwc_bwd")
+        return dx, None, None, None, None, None, None
+
+
+def instance_norm_cl(x, gamma, beta, eps=1e-5, act=ACT_NONE, slope=0.01, out=None):
+    return _InstNormClFn.apply(x, gamma, beta, eps, act, slope, out)
+
+
+class _ConvTClFn(torch.autograd.Function):
+    """nn.ConvTranspose2d on channels-last tensors (graph/decoder.py:73-77,116-120): forward is the stride-phase
+    data-gradient kernel of csrc/conv_nhwc.inc, d/dx the forward-conv kernel; the weight is stored
+    [Cin, KH, KW, Cout] (torch.channels_last of the [Cin, Cout, KH, KW] parameter)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, opad, act, slope, out):
+        xct = _need_cl(x, "conv_transpose2d (channels-last)")
+        _cl_weight(w, "conv_transpose2d (channels-last)")
+        N, Ci, h, wd = x.shape
+        _, Co, KH, KW = w.shape
+        OH = (h - 1) * stride[0] - 2 * pad[0] + KH + opad[0]
+        OW = (wd - 1) * stride[1] - 2 * pad[1] + KW + opad[1]
+        y = out if out is not None else new_channels_last(N, Co, OH, OW, x.device)
+        yct = _need_cl(y, "conv_transpose2d output")
+        k = (KH, KW)
+        # conv geometry: X = y (image side, Cx = Co), Y = x (feature side, Cy = Ci)
+        d = _desc(N, Co, OH, OW, Ci, h, wd, k, stride, pad, yct, xct, act, slope)
+        nat.check(nat.lib().mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "convT_nhwc_fwd")
+        ctx.geom = (N, Co, OH, OW, Ci, h, wd, k, stride, pad, xct, act, slope)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.b = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, Co, OH, OW, Ci, h, wd, k, s, p, xct, act, slope = ctx.geom
+        L = nat.lib()
+        if _trunk_streams or _used_sides:
+            _ensure_join_callback()
+        if cl_pitch(dy) is None:
+            dy = dy.contiguous(memory_format=CL)
+        if act != ACT_NONE:
+            dy = _act_bwd_cl(y, dy, act, slope)
+        dct = _need_cl(dy, "conv_transpose2d (channels-last) backward")
+        b = ctx.b
+
+        def weight_grads():
+            if w.requires_grad:
+                d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
+                nat.check(L.mgvae_conv2d_nhwc_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_nhwc_bwd_weight")
+            if b is not None and b.requires_grad:
+                nat.check(L.mgvae_channel_sum_nhwc_accum(_p(dy), N * OH * OW, Co, dct, 0, _p(grad_slot(b)), _s()), "bias_grad_nhwc")
+
+        if FORK_WGRAD and N >= FORK_MIN_BATCH and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
+            _wgrad_rr[0] += 1
+            with _forked(x, dy, slot=2 + _wgrad_rr[0] % WGRAD_STREAMS):
+                weight_grads()
+        else:
+            weight_grads()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_channels_last(N, Ci, h, wd, dy.device)
+            d2 = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, Ci, ACT_NONE, 0.0)
+            nat.check(L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), None, _s()), "convT_nhwc_bwd_data")
+        return dx, None, None, None, None, None, None, None, None
+
+
+def conv_transpose2d_cl(x, w, b=None, stride=(1, 1), pad=(0, 0), opad=(0, 0), act=ACT_NONE, slope=0.01, out=None):
+    return _ConvTClFn.apply(x, w, b, stride, pad, opad, act, slope, out)
