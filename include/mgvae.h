@@ -121,6 +121,17 @@ int mgvae_conv2d_nhwc_fwd(const MgvaeConvDesc* d, const float* x, const float* w
 int mgvae_conv2d_nhwc_bwd_data(const MgvaeConvDesc* d, const float* y, const float* w, const float* bias, float* x,
                                const MgvaeActMask* mask, void* stream);
 int mgvae_conv2d_nhwc_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw, void* stream);
+/* bf16-STORAGE forms (BASELINE.json configs 3-4): x / y are bf16 channels-last tensors (passed as void*; a mask's `src`
+ * then points at bf16 too), the two weight operands are bf16 copies of the fp32 channels-last master made once per
+ * optimizer step by mgvae_pack_conv_weights_bf16 -- wk [Cy, KH*KW, Cx] for the forward, wt [Cx, KH*KW, Cy] for the data
+ * gradient -- bias fp32, accumulation fp32 (v_mfma_f32_32x32x16_bf16), the weight gradient is ADDED to the fp32 master
+ * gradient dw [Cy, KH*KW, Cx].  Channel counts multiples of 64, slice offsets multiples of 8 (csrc/conv_nhwc_bf16.inc).   */
+int mgvae_pack_conv_weights_bf16(const float* w, void* wk, void* wt, int Cy, int T, int Cx, void* stream);
+int mgvae_conv2d_nhwc_bf16_fwd(const MgvaeConvDesc* d, const void* x, const void* wk, const float* bias, void* y,
+                               const MgvaeActMask* mask, void* stream);
+int mgvae_conv2d_nhwc_bf16_bwd_data(const MgvaeConvDesc* d, const void* y, const void* wt, const float* bias, void* x,
+                                    const MgvaeActMask* mask, void* stream);
+int mgvae_conv2d_nhwc_bf16_bwd_weight(const MgvaeConvDesc* d, const void* x, const void* y, float* dw, void* stream);
 
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                             void* stream);
@@ -198,34 +209,39 @@ int mgvae_cbam_bwd(const float* u, const float* y, const float* dy, const float*
  * 110-126 on tensors stored [N, H, W, C]): x [N, P, C] dense (a conv output), res / y / dy channel slices (ctot, coff) of
  * channels-last buffers, dres / dx dense.  C in {64, 128, 256, 512, 1024}.  u = gamma * xhat + beta is recomputed from x
  * in every pass instead of being stored (csrc/norm_cbam_nhwc.inc).  `save` / `scratch`: workspaces of the sizes the two
- * functions below return (floats, 16-byte aligned).  Weight-like gradients accumulate.                                   */
+ * functions below return (floats, 16-byte aligned).  Weight-like gradients accumulate (fp32).
+ * `storage`: element type of the big tensors (x, res, y, dy, dx, dres), passed as void*: MGVAE_STORE_F32, or
+ * MGVAE_STORE_BF16 for the bf16-storage mode of BASELINE.json configs 3-4 (statistics, gates, arithmetic stay fp32).    */
+enum { MGVAE_STORE_F32 = 0, MGVAE_STORE_BF16 = 1 };
 size_t mgvae_norm_cbam_nhwc_save_floats(int N, int C, int H, int W);
 size_t mgvae_norm_cbam_nhwc_scratch_floats(int N, int C, int H, int W);
-int mgvae_norm_cbam_nhwc_fwd(const float* x, const float* gamma, const float* beta, const float* res, int res_ctot,
-                             int res_coff, const float* w1, const float* w2, const float* wsp, float* y, float* save,
+int mgvae_norm_cbam_nhwc_fwd(const void* x, const float* gamma, const float* beta, const void* res, int res_ctot,
+                             int res_coff, const float* w1, const float* w2, const float* wsp, void* y, float* save,
                              int N, int C, int H, int W, int y_ctot, int y_coff, float eps, int mode, int act,
-                             float slope, void* stream);
-int mgvae_norm_cbam_nhwc_bwd(const float* x, const float* gamma, const float* beta, const float* y, const float* dy,
-                             const float* w1, const float* w2, const float* wsp, const float* save, float* dx,
-                             float* dres, float* dgamma, float* dbeta, float* dw1, float* dw2, float* dwsp,
+                             float slope, int storage, void* stream);
+int mgvae_norm_cbam_nhwc_bwd(const void* x, const float* gamma, const float* beta, const void* y, const void* dy,
+                             const float* w1, const float* w2, const float* wsp, const float* save, void* dx,
+                             void* dres, float* dgamma, float* dbeta, float* dw1, float* dw2, float* dwsp,
                              float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff, int mode, int act,
-                             float slope, void* stream);
+                             float slope, int storage, void* stream);
 /* InstanceNorm2d (+ReLU / LeakyReLU) alone on channels-last tensors (graph/decoder.py:81-83,124-126); `stats`: 6 N C
  * floats kept for backward, `scratch`: 2 N C floats; and the bias gradient of a transposed conv (sum over pixel rows).   */
-int mgvae_instance_norm_nhwc_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int N,
-                                 int C, int H, int W, int y_ctot, int y_coff, float eps, int act, float slope, void* stream);
-int mgvae_instance_norm_nhwc_bwd(const float* x, const float* gamma, const float* stats, const float* y, const float* dy,
-                                 float* dx, float* dgamma, float* dbeta, float* scratch, int N, int C, int H, int W,
-                                 int y_ctot, int y_coff, int act, float slope, void* stream);
-int mgvae_channel_sum_nhwc_accum(const float* t, long rows, int C, int ctot, int coff, float* db, void* stream);
-/* layout changes at the ends of a channels-last island (channel slices on both sides) and the whole-map average of a
- * channels-last tensor [N, P, C] -> [N, C] (graph/encoder.py:35, graph/phrase_encoder.py:36) with its gradient */
-int mgvae_layout_nchw_to_nhwc(const float* src, float* dst, int N, int C, int P, int src_ctot, int src_coff,
-                              int dst_ctot, int dst_coff, void* stream);
-int mgvae_layout_nhwc_to_nchw(const float* src, float* dst, int N, int C, int P, int src_ctot, int src_coff,
-                              int dst_ctot, int dst_coff, void* stream);
-int mgvae_mean_nhwc_fwd(const float* x, float* out, int N, int C, int P, void* stream);
-int mgvae_mean_nhwc_bwd(const float* dout, float* dx, int N, int C, int P, void* stream);
+int mgvae_instance_norm_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N,
+                                 int C, int H, int W, int y_ctot, int y_coff, float eps, int act, float slope, int storage,
+                                 void* stream);
+int mgvae_instance_norm_nhwc_bwd(const void* x, const float* gamma, const float* stats, const void* y, const void* dy,
+                                 void* dx, float* dgamma, float* dbeta, float* scratch, int N, int C, int H, int W,
+                                 int y_ctot, int y_coff, int act, float slope, int storage, void* stream);
+int mgvae_channel_sum_nhwc_accum(const void* t, long rows, int C, int ctot, int coff, float* db, int storage, void* stream);
+/* layout changes at the ends of a channels-last island (channel slices on both sides; the NCHW side is always fp32, the
+ * channels-last side has the `storage` type) and the whole-map average of a channels-last tensor [N, P, C] -> fp32 [N, C]
+ * (graph/encoder.py:35, graph/phrase_encoder.py:36) with its gradient */
+int mgvae_layout_nchw_to_nhwc(const float* src, void* dst, int N, int C, int P, int src_ctot, int src_coff,
+                              int dst_ctot, int dst_coff, int storage, void* stream);
+int mgvae_layout_nhwc_to_nchw(const void* src, float* dst, int N, int C, int P, int src_ctot, int src_coff,
+                              int dst_ctot, int dst_coff, int storage, void* stream);
+int mgvae_mean_nhwc_fwd(const void* x, float* out, int N, int C, int P, int storage, void* stream);
+int mgvae_mean_nhwc_bwd(const float* dout, void* dx, int N, int C, int P, int storage, void* stream);
 
 /* dx = dy * act'(y) given the activation OUTPUT y (ReLU/LeakyReLU/Sigmoid); all three
  * tensors may be channel slices of [N, ctot, P] buffers                               */
@@ -314,8 +330,9 @@ int mgvae_bf16_rows_sum(const void* rows_bf16, void* dst_bf16, int R, size_t n, 
  * {kind (0 fwd,1 bwd_data,2 bwd_weight igemm; 3 fwd,4 bwd_data direct), tile id, launches, total ms, total flops}.
  * Kinds 5..7 are the HBM-bound kernels (flat Adam, InstanceNorm forward / backward): their `flops` field carries the
  * ALGORITHMIC BYTES of the launch instead (Adam 7 x 4n; InstanceNorm 2 x / 3 x 4 N C P).
- * Kinds 8..10: the channels-last implicit-GEMM kernels (forward, data gradient, weight gradient).                       */
-enum { MGVAE_PROF_ADAM = 5, MGVAE_PROF_INORM_FWD = 6, MGVAE_PROF_INORM_BWD = 7, MGVAE_PROF_NHWC_FWD = 8, MGVAE_PROF_KINDS = 11 };
+ * Kinds 8..10: the channels-last implicit-GEMM kernels (forward, data gradient, weight gradient); 11..13: their bf16 forms. */
+enum { MGVAE_PROF_ADAM = 5, MGVAE_PROF_INORM_FWD = 6, MGVAE_PROF_INORM_BWD = 7, MGVAE_PROF_NHWC_FWD = 8, MGVAE_PROF_NHWC_BF16_FWD = 11,
+       MGVAE_PROF_KINDS = 14 };
 typedef struct MgvaeProfRec { int32_t kind, tile, launches; double ms, flops; } MgvaeProfRec;
 int mgvae_prof_enable(int on);
 int mgvae_prof_collect(MgvaeProfRec* out, int cap);

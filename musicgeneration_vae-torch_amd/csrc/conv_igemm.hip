@@ -1901,10 +1901,11 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
     static char buf[5][7][48];
-    static char nbuf[3][7][48];
-    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 3 && tile >= 0 && tile < 4) {
-        snprintf(nbuf[kind - MGVAE_PROF_NHWC_FWD][tile], 48, "nhwc_igemm_kernel<%d, %s>", kind - MGVAE_PROF_NHWC_FWD, tiles[tile]);
-        return nbuf[kind - MGVAE_PROF_NHWC_FWD][tile];
+    static char nbuf[6][7][48];
+    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 6 && tile >= 0 && tile < 4) {
+        const int m = kind - MGVAE_PROF_NHWC_FWD;
+        snprintf(nbuf[m][tile], 48, m < 3 ? "nhwc_igemm_kernel<%d, %s>" : "nhwc_igemm_bf16_kernel<%d, %s>", m % 3, tiles[tile]);
+        return nbuf[m][tile];
     }
     if (kind == MGVAE_PROF_ADAM) return "adam_kernel";
     if (kind == MGVAE_PROF_INORM_FWD) return "instance_norm_fwd_*";
@@ -1943,3 +1944,4 @@ extern "C" const char* mgvae_strerror(int code) {
 }
 
 #include "conv_nhwc.inc"
+#include "conv_nhwc_bf16.inc"

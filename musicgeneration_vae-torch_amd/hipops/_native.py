@@ -26,7 +26,7 @@ class ActMask(ctypes.Structure):
                 ("slope", ctypes.c_float)]
 
 
-class ProfRec(ctypes.Structure):
+class ProfRec(ctypes.Structure):  # noqa: E302
     _fields_ = [("kind", ctypes.c_int32), ("tile", ctypes.c_int32), ("launches", ctypes.c_int32),
                 ("ms", ctypes.c_double), ("flops", ctypes.c_double)]
 
@@ -49,6 +49,10 @@ SIGNATURES = {
     "mgvae_conv2d_nhwc_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
+    "mgvae_pack_conv_weights_bf16": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "mgvae_conv2d_nhwc_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_bf16_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_bf16_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),
     "mgvae_conv2d_fwd_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
@@ -66,15 +70,15 @@ SIGNATURES = {
     "mgvae_cbam_bwd": (c_int, [P] * 13 + [c_int] * 8 + [c_float, c_int, P]),
     "mgvae_norm_cbam_nhwc_save_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_norm_cbam_nhwc_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "mgvae_norm_cbam_nhwc_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_int, c_float, P]),
-    "mgvae_norm_cbam_nhwc_bwd": (c_int, [P] * 17 + [c_int] * 8 + [c_float, P]),
-    "mgvae_instance_norm_nhwc_fwd": (c_int, [P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_float, P]),
-    "mgvae_instance_norm_nhwc_bwd": (c_int, [P] * 9 + [c_int] * 7 + [c_float, P]),
-    "mgvae_channel_sum_nhwc_accum": (c_int, [P, ctypes.c_long, c_int, c_int, c_int, P, P]),
-    "mgvae_layout_nchw_to_nhwc": (c_int, [P, P] + [c_int] * 7 + [P]),
-    "mgvae_layout_nhwc_to_nchw": (c_int, [P, P] + [c_int] * 7 + [P]),
-    "mgvae_mean_nhwc_fwd": (c_int, [P, P, c_int, c_int, c_int, P]),
-    "mgvae_mean_nhwc_bwd": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "mgvae_norm_cbam_nhwc_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_int, c_float, c_int, P]),
+    "mgvae_norm_cbam_nhwc_bwd": (c_int, [P] * 17 + [c_int] * 8 + [c_float, c_int, P]),
+    "mgvae_instance_norm_nhwc_fwd": (c_int, [P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_float, c_int, P]),
+    "mgvae_instance_norm_nhwc_bwd": (c_int, [P] * 9 + [c_int] * 7 + [c_float, c_int, P]),
+    "mgvae_channel_sum_nhwc_accum": (c_int, [P, ctypes.c_long, c_int, c_int, c_int, P, c_int, P]),
+    "mgvae_layout_nchw_to_nhwc": (c_int, [P, P] + [c_int] * 8 + [P]),
+    "mgvae_layout_nhwc_to_nchw": (c_int, [P, P] + [c_int] * 8 + [P]),
+    "mgvae_mean_nhwc_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "mgvae_mean_nhwc_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "mgvae_act_bwd": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
     "mgvae_copy2d": (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     "mgvae_add_inplace": (c_int, [P, P, c_size_t, P]),

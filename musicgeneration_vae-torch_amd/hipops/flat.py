@@ -49,8 +49,12 @@ class FlatParams:
                 g = self._view(self.grad, p, o)
                 p._mg_grad = g
                 p.grad = g
+                p._mg_owner = self
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
+        # counts every update of the flat weights by ANY Adam state over them (second_state shares it): derived copies of
+        # the weights (the bf16 operands of the channels-last convs) are refreshed when it moves
+        self.weights_version = [0]
         # step-dependent scalars travel through a RING of pinned rows: the host runs several steps ahead of the GPU, and
         # an async copy of step n must not find the scalars of step n+1 in its source
         self._hyper_ring = torch.zeros(_HYPER_RING, 4, dtype=torch.float32).pin_memory()
@@ -82,6 +86,7 @@ class FlatParams:
     def begin_step(self):
         """count the step and upload its scalars (lr / bias corrections) on the current stream"""
         self.step_count += 1
+        self.weights_version[0] += 1
         lr = self.param_groups[0]["lr"]
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.step_count
@@ -144,6 +149,7 @@ class FlatParams:
         o.exp_avg, o.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         o.lr, o.betas, o.eps = (lr if lr is not None else self.lr), self.betas, self.eps
         o.step_count = 0
+        o.weights_version = self.weights_version
         o._hyper_ring = torch.zeros(_HYPER_RING, 4, dtype=torch.float32).pin_memory()
         o._hyper_host = o._hyper_ring[0]
         o._hyper = torch.zeros(4, device=self.flat.device, dtype=torch.float32)

@@ -1075,13 +1075,28 @@ def reparam_kl(mean, logvar, eps=None):
 # ====================================================================== channels-last (NHWC) family
 # Activations stored [N, H, W, C] and conv weights stored [Cy, KH, KW, Cx] -- torch.channels_last for both, so logical
 # shapes, state_dict entries and everything that indexes tensors logically (tests, checkpoints) are unchanged.  The GEMM's
-# K axis (tap, channel) is then contiguous in memory: csrc/conv_nhwc.inc.  The encoder trunks run in this layout
-# (graph/encoder.py); ``to_channels_last`` / ``to_nchw`` convert at the ends of such an island.
+# K axis (tap, channel) is then contiguous in memory: csrc/conv_nhwc.inc.  The encoder trunks and the decoder's blocks run
+# in this layout (graph/encoder.py, graph/decoder.py); ``to_channels_last`` / ``to_nchw`` convert at the ends of the island.
+#
+# Storage type of the island: fp32, or -- with set_compute_dtype("bf16"), BASELINE.json configs 3-4 -- bf16: activations
+# and their gradients are bf16 tensors, the convs run on the bf16 matrix pipe from bf16 copies of the fp32 master weights
+# (csrc/conv_nhwc_bf16.inc), statistics / gates / accumulators / weight gradients / Adam stay fp32.  The ops below take the
+# storage type from the tensors they are given.
 CL = torch.channels_last
+STORE_F32, STORE_BF16 = 0, 1
+
+
+def island_dtype():
+    """storage type of channels-last activations created at the entry of an island"""
+    return torch.bfloat16 if get_compute_dtype() == "bf16" else torch.float32
+
+
+def _store(t):
+    return STORE_BF16 if t.dtype == torch.bfloat16 else STORE_F32
 
 
 def cl_pitch(t):
-    """channel pitch (floats between consecutive pixels) of an NCHW-shaped tensor whose memory is channels-last --
+    """channel pitch (elements between consecutive pixels) of an NCHW-shaped tensor whose memory is channels-last --
     dense, or a channel slice of a wider channels-last buffer; None for any other layout"""
     n, c, h, w = t.shape
     st = t.stride()
@@ -1100,14 +1115,17 @@ def cl_pitch(t):
     return ct
 
 
-def new_channels_last(n, c, h, w, device):
-    return torch.empty((n, h, w, c), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+def new_channels_last(n, c, h, w, device, dtype=torch.float32):
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
 
 
 def _need_cl(t, what):
-    _need_cuda(t, what)
+    if not t.is_cuda:
+        raise RuntimeError("%s: expected a ROCm device tensor; the MI355X hot path has no CPU fallback" % what)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("%s: expected float32 or bfloat16, got %s" % (what, t.dtype))
     ct = cl_pitch(t)
-    if ct is None or (ct % 4) or (t.data_ptr() % 16):
+    if ct is None or (ct % (8 if t.dtype == torch.bfloat16 else 4)) or (t.data_ptr() % 16):
         raise RuntimeError("%s: expected a channels-last tensor (stride %s of shape %s is not)" % (what, t.stride(), tuple(t.shape)))
     return ct
 
@@ -1124,16 +1142,37 @@ def _cl_mask(t, act, slope):
     return nat.ActMask(t.data_ptr(), ct, 0, act, slope), t
 
 
+def _bf16_weights(w):
+    """(wk, wt): bf16 copies of the fp32 channels-last master weight ``w`` -- wk [Cy, T, Cx] for the forward product, wt
+    [Cx, T, Cy] for the data gradient -- repacked once per optimizer step (FlatParams counts the steps; a parameter outside
+    a flat buffer is repacked whenever torch's version counter moves)."""
+    owner = getattr(w, "_mg_owner", None)
+    ver = (owner.weights_version[0] if owner is not None else -1, w._version, w.data_ptr())
+    c = getattr(w, "_mg_bf16", None)
+    if c is None or c[0] != ver or torch.cuda.is_current_stream_capturing():
+        cy, cx, kh, kw = w.shape
+        if c is None:
+            wk = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+            wt = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
+        else:
+            wk, wt = c[1], c[2]
+        nat.check(nat.lib().mgvae_pack_conv_weights_bf16(_p(w), _p(wk), _p(wt), cy, kh * kw, cx, _s()), "pack_conv_weights_bf16")
+        c = (ver, wk, wt)
+        w._mg_bf16 = c
+    return c[1], c[2]
+
+
 class _ToChannelsLastFn(torch.autograd.Function):
-    """NCHW (dense or a channel slice) -> dense channels-last copy; backward converts the gradient back"""
+    """NCHW fp32 (dense or a channel slice) -> dense channels-last copy of the island's storage type; backward converts the
+    gradient back to NCHW fp32"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, dtype):
         _need_cuda(x, "to_channels_last")
         x, xct = _sliceable(x)
         N, C, H, W = x.shape
-        y = new_channels_last(N, C, H, W, x.device)
-        nat.check(nat.lib().mgvae_layout_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, xct, 0, C, 0, _s()), "nchw_to_nhwc")
+        y = new_channels_last(N, C, H, W, x.device, dtype)
+        nat.check(nat.lib().mgvae_layout_nchw_to_nhwc(_p(x), _p(y), N, C, H * W, xct, 0, C, 0, _store(y), _s()), "nchw_to_nhwc")
         return y
 
     @staticmethod
@@ -1141,8 +1180,8 @@ class _ToChannelsLastFn(torch.autograd.Function):
         ct = _need_cl(dy, "to_channels_last backward")
         N, C, H, W = dy.shape
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
-        nat.check(nat.lib().mgvae_layout_nhwc_to_nchw(_p(dy), _p(dx), N, C, H * W, ct, 0, C, 0, _s()), "nhwc_to_nchw")
-        return dx
+        nat.check(nat.lib().mgvae_layout_nhwc_to_nchw(_p(dy), _p(dx), N, C, H * W, ct, 0, C, 0, _store(dy), _s()), "nhwc_to_nchw")
+        return dx, None
 
 
 class _ToNchwFn(torch.autograd.Function):
@@ -1151,30 +1190,40 @@ class _ToNchwFn(torch.autograd.Function):
         ct = _need_cl(x, "to_nchw")
         N, C, H, W = x.shape
         y = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
-        nat.check(nat.lib().mgvae_layout_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, ct, 0, C, 0, _s()), "nhwc_to_nchw")
+        nat.check(nat.lib().mgvae_layout_nhwc_to_nchw(_p(x), _p(y), N, C, H * W, ct, 0, C, 0, _store(x), _s()), "nhwc_to_nchw")
+        ctx.dtype = x.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy, dct = _sliceable(dy)
         N, C, H, W = dy.shape
-        dx = new_channels_last(N, C, H, W, dy.device)
-        nat.check(nat.lib().mgvae_layout_nchw_to_nhwc(_p(dy), _p(dx), N, C, H * W, dct, 0, C, 0, _s()), "nchw_to_nhwc")
+        dx = new_channels_last(N, C, H, W, dy.device, ctx.dtype)
+        nat.check(nat.lib().mgvae_layout_nchw_to_nhwc(_p(dy), _p(dx), N, C, H * W, dct, 0, C, 0, _store(dx), _s()), "nchw_to_nhwc")
         return dx
 
 
-def to_channels_last(x):
-    return _ToChannelsLastFn.apply(x)
+def to_channels_last(x, dtype=None):
+    return _ToChannelsLastFn.apply(x, dtype if dtype is not None else island_dtype())
 
 
 def to_nchw(x):
     return _ToNchwFn.apply(x)
 
 
+def _as_cl(t, like):
+    """gradient tensor ``t`` as a channels-last tensor of ``like``'s storage type (autograd may hand over another layout)"""
+    if t.dtype != like.dtype:
+        t = t.to(like.dtype)
+    if cl_pitch(t) is None:
+        t = t.contiguous(memory_format=CL)
+    return t
+
+
 class _ConvClFn(torch.autograd.Function):
     """nn.Conv2d on channels-last tensors (graph/encodingBlock.py:74-77,107-108): forward, data gradient (stride
-    phases) and weight gradient of csrc/conv_nhwc.inc; the weight is stored [Cy, KH, KW, Cx] and its gradient is
-    accumulated in that same layout."""
+    phases) and weight gradient of csrc/conv_nhwc.inc (fp32) / csrc/conv_nhwc_bf16.inc (bf16 storage); the weight is
+    stored [Cy, KH, KW, Cx] and its gradient is accumulated in that same layout (fp32 in both modes)."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, act, slope, out, in_act=None, defer_act_grad=False):
@@ -1184,10 +1233,14 @@ class _ConvClFn(torch.autograd.Function):
         Cy, _, KH, KW = w.shape
         OH = (H + 2 * pad[0] - KH) // stride[0] + 1
         OW = (W + 2 * pad[1] - KW) // stride[1] + 1
-        y = out if out is not None else new_channels_last(N, Cy, OH, OW, x.device)
+        y = out if out is not None else new_channels_last(N, Cy, OH, OW, x.device, x.dtype)
         yct = _need_cl(y, "conv2d (channels-last) output")
         d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
-        nat.check(nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "conv2d_nhwc_fwd")
+        if x.dtype == torch.bfloat16:
+            wk, _ = _bf16_weights(w)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), _p(x), _p(wk), _p(b), _p(y), None, _s()), "conv2d_nhwc_bf16_fwd")
+        else:
+            nat.check(nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "conv2d_nhwc_fwd")
         ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
         if not DEFER_ACT_GRAD:
             in_act, defer_act_grad = None, False
@@ -1201,10 +1254,10 @@ class _ConvClFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, Cx, H, W, Cy, OH, OW, k, s, p, xct, act, slope = ctx.geom
         L = nat.lib()
+        bf = x.dtype == torch.bfloat16
         if _trunk_streams or _used_sides:
             _ensure_join_callback()
-        if cl_pitch(dy) is None:
-            dy = dy.contiguous(memory_format=CL)
+        dy = _as_cl(dy, x)
         if act != ACT_NONE and not ctx.defer:
             dy = _act_bwd_cl(y, dy, act, slope)
         dct = _need_cl(dy, "conv2d (channels-last) backward")
@@ -1213,9 +1266,10 @@ class _ConvClFn(torch.autograd.Function):
 
         def weight_grads():
             if w.requires_grad:
-                nat.check(L.mgvae_conv2d_nhwc_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_nhwc_bwd_weight")
+                fn = L.mgvae_conv2d_nhwc_bf16_bwd_weight if bf else L.mgvae_conv2d_nhwc_bwd_weight
+                nat.check(fn(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_nhwc_bwd_weight")
             if b is not None and b.requires_grad:
-                raise RuntimeError("channels-last conv: bias gradient not implemented (the trunk convs have no bias)")
+                nat.check(L.mgvae_channel_sum_nhwc_accum(_p(dy), N * OH * OW, Cy, dct, 0, _p(grad_slot(b)), _store(dy), _s()), "bias_grad_nhwc")
 
         if FORK_WGRAD and N >= FORK_MIN_BATCH and ctx.needs_input_grad[0] and w.requires_grad:
             _wgrad_rr[0] += 1
@@ -1225,24 +1279,27 @@ class _ConvClFn(torch.autograd.Function):
             weight_grads()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = new_channels_last(N, Cx, H, W, dy.device)
+            dx = new_channels_last(N, Cx, H, W, dy.device, x.dtype)
             d2 = _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, Cx, dct, ACT_NONE, 0.0)
             m = None
             if ctx.in_act:
                 m, keep = _cl_mask(x, *ctx.in_act)
-            nat.check(L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), ctypes.byref(m) if m is not None else None,
-                                                   _s()), "conv2d_nhwc_bwd_data")
+            mref = ctypes.byref(m) if m is not None else None
+            if bf:
+                _, wt = _bf16_weights(w)
+                nat.check(L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d2), _p(dy), _p(wt), None, _p(dx), mref, _s()), "conv2d_nhwc_bf16_bwd_data")
+            else:
+                nat.check(L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), mref, _s()), "conv2d_nhwc_bwd_data")
         return dx, None, None, None, None, None, None, None, None, None
 
 
 def _act_bwd_cl(y, dy, act, slope):
-    """dx = dy * act'(y) for channels-last tensors (dense result).  Elementwise over pixel rows: the NCHW kernel with the
-    roles of the axes swapped (rows of C channels at a pitch)"""
+    """dx = dy * act'(y) for fp32 channels-last tensors (dense result): the NCHW kernel with rows of C channels at a pitch"""
+    if y.dtype != torch.float32:
+        raise RuntimeError("act_bwd on bf16 channels-last tensors is not on the hot path (activations are fused or deferred there)")
     yct = _need_cl(y, "act_bwd"); dct = _need_cl(dy, "act_bwd")
     n, c, h, w = y.shape
     dx = new_channels_last(n, c, h, w, y.device)
-    # [N*H*W rows, C] with row pitches: mgvae_act_bwd addresses [N', C', P'] tensors as ((n * ctot + coff + c) * P + p);
-    # with N' = rows, C' = 1... the pitch must be per row: use P' = 1 and ctot = pitch
     rows = n * h * w
     nat.check(nat.lib().mgvae_act_bwd(_p(y), _p(dy), _p(dx), rows, c, 1, yct, 0, dct, 0, c, 0, act, slope, _s()), "act_bwd")
     return dx
@@ -1265,12 +1322,14 @@ class _NormCbamClFn(torch.autograd.Function):
         rct = 0
         if res is not None:
             rct = _need_cl(res, "norm_cbam residual")
+            if res.dtype != x.dtype:
+                raise RuntimeError("norm_cbam (channels-last): residual and input differ in storage type")
         L = nat.lib()
-        y = out if out is not None else new_channels_last(N, C, H, W, x.device)
+        y = out if out is not None else new_channels_last(N, C, H, W, x.device, x.dtype)
         yct = _need_cl(y, "norm_cbam output")
         save = torch.empty((L.mgvae_norm_cbam_nhwc_save_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
         nat.check(L.mgvae_norm_cbam_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(res), rct, 0, _p(w1), _p(w2), _p(wsp), _p(y), _p(save),
-                                             N, C, H, W, yct, 0, eps, mode, act, slope, _s()), "norm_cbam_nhwc_fwd")
+                                             N, C, H, W, yct, 0, eps, mode, act, slope, _store(x), _s()), "norm_cbam_nhwc_fwd")
         ctx.save_for_backward(x, gamma, beta, y, w1, w2, wsp, save)
         ctx.cfg = (mode, act, slope)
         return y
@@ -1282,10 +1341,11 @@ class _NormCbamClFn(torch.autograd.Function):
         N, C, H, W = x.shape
         L = nat.lib()
         yct = cl_pitch(y)
+        dy = _as_cl(dy, x)
         if cl_pitch(dy) != yct:          # the kernels address y and dy with one pitch
             y = y.contiguous(memory_format=CL); dy = dy.contiguous(memory_format=CL); yct = C
-        dx = new_channels_last(N, C, H, W, x.device)
-        dres = new_channels_last(N, C, H, W, x.device) if mode == 2 else None
+        dx = new_channels_last(N, C, H, W, x.device, x.dtype)
+        dres = new_channels_last(N, C, H, W, x.device, x.dtype) if mode == 2 else None
         scratch = torch.empty((L.mgvae_norm_cbam_nhwc_scratch_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
         dg = grad_slot(gamma) if gamma.requires_grad else None
         db = grad_slot(beta) if beta.requires_grad else None
@@ -1294,7 +1354,7 @@ class _NormCbamClFn(torch.autograd.Function):
         dws = grad_slot(wsp) if wsp.requires_grad else None
         nat.check(L.mgvae_norm_cbam_nhwc_bwd(_p(x), _p(gamma), _p(beta), _p(y), _p(dy), _p(w1), _p(w2), _p(wsp), _p(save), _p(dx),
                                              _p(dres), _p(dg), _p(db), _p(dw1), _p(dw2), _p(dws), _p(scratch), N, C, H, W, yct, 0,
-                                             mode, act, slope, _s()), "norm_cbam_nhwc_bwd")
+                                             mode, act, slope, _store(x), _s()), "norm_cbam_nhwc_bwd")
         return (dx, None, None, dres) + (None,) * 8
 
 
@@ -1303,7 +1363,7 @@ def norm_cbam_cl(x, gamma, beta, w1, w2, wsp, eps=1e-5, mode=0, res=None, act=AC
 
 
 class _MeanClFn(torch.autograd.Function):
-    """whole-map average of a channels-last tensor (graph/encoder.py:20,35)"""
+    """whole-map average of a channels-last tensor -> fp32 [N, C] (graph/encoder.py:20,35)"""
 
     @staticmethod
     def forward(ctx, x):
@@ -1312,16 +1372,17 @@ class _MeanClFn(torch.autograd.Function):
         if ct != C:
             raise RuntimeError("global_avg_pool (channels-last): dense input expected")
         out = torch.empty((N, C), device=x.device, dtype=torch.float32)
-        nat.check(nat.lib().mgvae_mean_nhwc_fwd(_p(x), _p(out), N, C, H * W, _s()), "mean_nhwc_fwd")
+        nat.check(nat.lib().mgvae_mean_nhwc_fwd(_p(x), _p(out), N, C, H * W, _store(x), _s()), "mean_nhwc_fwd")
         ctx.shape = (N, C, H, W)
+        ctx.dtype = x.dtype
         return out
 
     @staticmethod
     def backward(ctx, dout):
         N, C, H, W = ctx.shape
         dout = dout.contiguous()
-        dx = new_channels_last(N, C, H, W, dout.device)
-        nat.check(nat.lib().mgvae_mean_nhwc_bwd(_p(dout), _p(dx), N, C, H * W, _s()), "mean_nhwc_bwd")
+        dx = new_channels_last(N, C, H, W, dout.device, ctx.dtype)
+        nat.check(nat.lib().mgvae_mean_nhwc_bwd(_p(dout), _p(dx), N, C, H * W, _store(dx), _s()), "mean_nhwc_bwd")
         return dx
 
 
@@ -1338,11 +1399,11 @@ class _InstNormClFn(torch.autograd.Function):
         N, C, H, W = x.shape
         if xct != C:
             raise RuntimeError("instance_norm (channels-last): the normalised tensor must be dense")
-        y = out if out is not None else new_channels_last(N, C, H, W, x.device)
+        y = out if out is not None else new_channels_last(N, C, H, W, x.device, x.dtype)
         yct = _need_cl(y, "instance_norm output")
         stats = torch.empty((6 * N * C,), device=x.device, dtype=torch.float32)
         nat.check(nat.lib().mgvae_instance_norm_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), N, C, H, W, yct, 0, eps, act,
-                                                         slope, _s()), "instance_norm_nhwc_fwd")
+                                                         slope, _store(x), _s()), "instance_norm_nhwc_fwd")
         ctx.save_for_backward(x, gamma, stats, y)
         ctx.beta = beta
         ctx.cfg = (act, slope)
@@ -1354,14 +1415,15 @@ class _InstNormClFn(torch.autograd.Function):
         act, slope = ctx.cfg
         N, C, H, W = x.shape
         yct = cl_pitch(y)
+        dy = _as_cl(dy, x)
         if cl_pitch(dy) != yct:
             y = y.contiguous(memory_format=CL); dy = dy.contiguous(memory_format=CL); yct = C
-        dx = new_channels_last(N, C, H, W, x.device)
+        dx = new_channels_last(N, C, H, W, x.device, x.dtype)
         scratch = torch.empty((2 * N * C,), device=x.device, dtype=torch.float32)
         dg = grad_slot(gamma) if gamma.requires_grad else None
         db = grad_slot(ctx.beta) if ctx.beta.requires_grad else None
         nat.check(nat.lib().mgvae_instance_norm_nhwc_bwd(_p(x), _p(gamma), _p(stats), _p(y), _p(dy), _p(dx), _p(dg), _p(db),
-                                                         _p(scratch), N, C, H, W, yct, 0, act, slope, _s()), "instance_norm_nhwc_bwd")
+                                                         _p(scratch), N, C, H, W, yct, 0, act, slope, _store(x), _s()), "instance_norm_nhwc_bwd")
         return dx, None, None, None, None, None, None
 
 
@@ -1382,12 +1444,16 @@ class _ConvTClFn(torch.autograd.Function):
         _, Co, KH, KW = w.shape
         OH = (h - 1) * stride[0] - 2 * pad[0] + KH + opad[0]
         OW = (wd - 1) * stride[1] - 2 * pad[1] + KW + opad[1]
-        y = out if out is not None else new_channels_last(N, Co, OH, OW, x.device)
+        y = out if out is not None else new_channels_last(N, Co, OH, OW, x.device, x.dtype)
         yct = _need_cl(y, "conv_transpose2d output")
         k = (KH, KW)
         # conv geometry: X = y (image side, Cx = Co), Y = x (feature side, Cy = Ci)
         d = _desc(N, Co, OH, OW, Ci, h, wd, k, stride, pad, yct, xct, act, slope)
-        nat.check(nat.lib().mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "convT_nhwc_fwd")
+        if x.dtype == torch.bfloat16:
+            _, wt = _bf16_weights(w)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), _p(x), _p(wt), _p(b), _p(y), None, _s()), "convT_nhwc_bf16_fwd")
+        else:
+            nat.check(nat.lib().mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "convT_nhwc_fwd")
         ctx.geom = (N, Co, OH, OW, Ci, h, wd, k, stride, pad, xct, act, slope)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.b = b
@@ -1398,10 +1464,10 @@ class _ConvTClFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, Co, OH, OW, Ci, h, wd, k, s, p, xct, act, slope = ctx.geom
         L = nat.lib()
+        bf = x.dtype == torch.bfloat16
         if _trunk_streams or _used_sides:
             _ensure_join_callback()
-        if cl_pitch(dy) is None:
-            dy = dy.contiguous(memory_format=CL)
+        dy = _as_cl(dy, x)
         if act != ACT_NONE:
             dy = _act_bwd_cl(y, dy, act, slope)
         dct = _need_cl(dy, "conv_transpose2d (channels-last) backward")
@@ -1410,9 +1476,10 @@ class _ConvTClFn(torch.autograd.Function):
         def weight_grads():
             if w.requires_grad:
                 d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
-                nat.check(L.mgvae_conv2d_nhwc_bwd_weight(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_nhwc_bwd_weight")
+                fn = L.mgvae_conv2d_nhwc_bf16_bwd_weight if bf else L.mgvae_conv2d_nhwc_bwd_weight
+                nat.check(fn(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_nhwc_bwd_weight")
             if b is not None and b.requires_grad:
-                nat.check(L.mgvae_channel_sum_nhwc_accum(_p(dy), N * OH * OW, Co, dct, 0, _p(grad_slot(b)), _s()), "bias_grad_nhwc")
+                nat.check(L.mgvae_channel_sum_nhwc_accum(_p(dy), N * OH * OW, Co, dct, 0, _p(grad_slot(b)), _store(dy), _s()), "bias_grad_nhwc")
 
         if FORK_WGRAD and N >= FORK_MIN_BATCH and ctx.needs_input_grad[0] and (w.requires_grad or (b is not None and b.requires_grad)):
             _wgrad_rr[0] += 1
@@ -1422,9 +1489,13 @@ class _ConvTClFn(torch.autograd.Function):
             weight_grads()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = new_channels_last(N, Ci, h, wd, dy.device)
+            dx = new_channels_last(N, Ci, h, wd, dy.device, x.dtype)
             d2 = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, Ci, ACT_NONE, 0.0)
-            nat.check(L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), None, _s()), "convT_nhwc_bwd_data")
+            if bf:
+                wk, _ = _bf16_weights(w)
+                nat.check(L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d2), _p(dy), _p(wk), None, _p(dx), None, _s()), "convT_nhwc_bf16_bwd_data")
+            else:
+                nat.check(L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), None, _s()), "convT_nhwc_bwd_data")
         return dx, None, None, None, None, None, None, None, None
 
 

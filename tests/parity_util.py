@@ -41,8 +41,11 @@ def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
                       against fp64 (SURVEY section 7 rule for ill-conditioned quantities);
       flip-noise      (needs ref32) a pre-activation within fp32 noise of 0 takes the other ReLU / arg-max branch than
                       in fp64 (torch fp32 does the same, at other places), which moves individual entries by O(1) and
-                      every entry of a small tensor that sums over whole maps (an 18-entry spatial-attention kernel) a
-                      little: the relative L2 error is <= max(1e-2, 3 x torch fp32's own L2 error);
+                      every entry of a small tensor that sums over whole maps (an 18-entry spatial-attention kernel, a
+                      gate-MLP weight) a little.  Large tensors: at most 2 % of the entries exceed the strict bound and
+                      the relative L2 error is <= max(1e-2, 3 x torch fp32's own L2 error).  Small aggregates (<= 4096
+                      entries): relative L2 error <= max(2e-2, 3 x torch fp32's own) -- the kernels behind them are
+                      pinned at 1e-3 one by one (measured ~1e-6), what is left is which way ties fall;
       flip-tolerant   only without ref32 (single kernels / blocks): at most 2 % of the entries exceed the strict bound
                       and the relative L2 error is <= 5e-2;
       l2              only without ref32: relative L2 error <= l2_ok (caller-supplied).
@@ -69,7 +72,9 @@ def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
             margin = mx / max(10 * e32 * scale, 1e-300)
         elif mx <= 3 * e32 * scale:
             rule, margin = "torch-limited", mx / max(3 * e32 * scale, 1e-300)
-        elif l2 <= max(1e-2, 3 * l2_32):
+        elif err.numel() <= 4096 and l2 <= max(2e-2, 3 * l2_32):
+            rule, margin = "flip-noise", l2 / max(2e-2, 3 * l2_32)
+        elif (frac <= 2e-2 or nbad <= 2) and l2 <= max(1e-2, 3 * l2_32):
             rule, margin = "flip-noise", l2 / max(1e-2, 3 * l2_32)
     else:
         if (frac <= 2e-2 or nbad <= 2) and l2 <= 5e-2:

@@ -287,3 +287,87 @@ def test_conv_transpose_channels_last_autograd(g):
     check("convT_cl dw %s" % (g,), wd.grad, wr.grad)
     if bias:
         check("convT_cl db %s" % (g,), bd.grad, br.grad)
+
+
+BF16_GEOMS = [  # N, Cx, H, W, Cy, k, s, p  (channel counts multiples of 64)
+    (3, 64, 48, 30, 64, 3, 1, 1), (2, 128, 24, 15, 128, 3, 1, 1), (3, 512, 6, 4, 512, 3, 1, 1), (3, 64, 48, 30, 128, 3, 2, 1),
+    (5, 128, 24, 15, 256, 3, 2, 1), (3, 2048, 6, 3, 1024, 1, 1, 0), (2, 128, 24, 15, 256, 4, 2, 1), (2, 64, 96, 60, 128, 3, 2, 1),
+    (1, 64, 5, 4, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("g", BF16_GEOMS, ids=lambda g: "x".join(map(str, g)))
+def test_nhwc_bf16_conv_three_products(g):
+    """bf16-storage channels-last family (BASELINE.json configs 3-4) through the C ABI: operands are bf16 tensors, the
+    reference multiplies the SAME bf16 values in fp64.  Forward / data gradient store bf16 (one rounding of the fp32
+    accumulator: 2^-9 relative per element -> 4e-3 of the largest entry), the weight gradient stays fp32 (1e-3)."""
+    from hipops import _native as nat
+    L = nat.lib()
+    N, Cx, H, W_, Cy, k, s, p = g
+    OH, OW = (H + 2 * p - k) // s + 1, (W_ + 2 * p - k) // s + 1
+    bf = lambda t: t.bfloat16()
+    x = bf(torch.randn(N, Cx, H, W_).relu_()); w = bf(torch.randn(Cy, Cx, k, k) * 0.2 - 0.05); b = torch.randn(Cy)
+    dy = bf(torch.randn(N, Cy, OH, OW))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.double(), stride=s, padding=p)
+    yr.backward(dy.double())
+    clb = lambda t: t.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # bf16 channels-last
+    xd, dyd = clb(x), clb(dy)
+    w32 = cl(w.float())                                                                  # fp32 master, channels-last
+    wk = torch.empty(Cy * k * k * Cx, device=dev, dtype=torch.bfloat16)
+    wt = torch.empty(Cy * k * k * Cx, device=dev, dtype=torch.bfloat16)
+    assert L.mgvae_pack_conv_weights_bf16(vp(w32), vp(wk), vp(wt), Cy, k * k, Cx, stream()) == 0
+    assert torch.equal(wk.view(Cy, k, k, Cx).permute(0, 3, 1, 2).cpu(), w)
+    assert torch.equal(wt.view(Cx, k, k, Cy).permute(3, 0, 1, 2).cpu(), w)
+    d = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, s, s, p, p, Cx, 0, Cy, 0, 0, 0.0)
+    yd = clb(torch.zeros(N, Cy, OH, OW).bfloat16())
+    assert L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), vp(xd), vp(wk), vp(b.to(dev)), vp(yd), None, stream()) == 0
+    check("nhwc bf16 fwd %s" % (g,), yd.float(), yr, 4e-3)
+    dx = clb(torch.zeros(N, Cx, H, W_).bfloat16())
+    assert L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), vp(dyd), vp(wt), None, vp(dx), None, stream()) == 0
+    check("nhwc bf16 dx %s" % (g,), dx.float(), xr.grad, 4e-3)
+    dw = cl(torch.ones(Cy, Cx, k, k))
+    assert L.mgvae_conv2d_nhwc_bf16_bwd_weight(ctypes.byref(d), vp(xd), vp(dyd), vp(dw), stream()) == 0
+    check("nhwc bf16 dw %s" % (g,), dw, 1.0 + wr.grad)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 48, 30), (2, 256, 12, 8), (2, 1024, 3, 2)])
+@pytest.mark.parametrize("mode,act", [(1, 1), (2, 1)])
+def test_norm_cbam_channels_last_bf16_storage(shape, mode, act):
+    """the fused InstanceNorm / CBAM op with bf16 STORAGE of the big tensors (statistics, gates, arithmetic fp32): against the
+    fp64 oracle evaluated on the SAME bf16 input values.  The output and dx are rounded to bf16 once (2^-9 per element);
+    inside the backward the partial du is stored in bf16 as well, so dx carries two roundings: 1e-2 of the largest entry."""
+    from hipops import functional as HF
+    from oracle import restate as R
+    N, C, H, W_ = shape
+    bf = lambda t: t.bfloat16()
+    x = bf(torch.randn(shape) * 2 + 0.5); res = bf(torch.randn(shape)); dy = bf(torch.randn(shape))
+    g = torch.randn(C); b = torch.randn(C)
+    sd = {"channel_attention.conv1.weight": torch.randn(C // 16, C, 1, 1) * 0.2,
+          "channel_attention.conv2.weight": torch.randn(C, C // 16, 1, 1) * 0.2,
+          "spatial_attention.conv.weight": torch.randn(1, 2, 3, 3) * 0.3}
+    sdr = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ur = F.instance_norm(xr, None, None, gr, br, True, 0.01, 1e-5)
+    o = R.cbam(sdr, "", ur)
+    yr = F.relu(ur + o) if mode == 1 else F.relu(rr + o)
+    yr.backward(dy.double())
+    clb = lambda t: t.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    xd = clb(x).requires_grad_(True); rd = clb(res).requires_grad_(True)
+    gd = torch.nn.Parameter(g.to(dev)); bd = torch.nn.Parameter(b.to(dev))
+    ps = {k: torch.nn.Parameter(v.to(dev)) for k, v in sd.items()}
+    y = HF.norm_cbam_cl(xd, gd, bd, ps["channel_attention.conv1.weight"], ps["channel_attention.conv2.weight"],
+                        ps["spatial_attention.conv.weight"], 1e-5, mode, rd if mode == 2 else None, act, 0.01)
+    assert y.dtype == torch.bfloat16
+    tag = "norm_cbam_cl bf16 %s mode%d" % (shape, mode)
+    check(tag + " fwd", y.float(), yr, 4e-3)
+    # the reference's y differs from the stored bf16 y by one rounding; ReLU masks are read from the stored y
+    y.backward(clb(dy))
+    assert xd.grad.dtype == torch.bfloat16
+    check(tag + " dx", xd.grad.float(), xr.grad, 1e-2)
+    check(tag + " dgamma", gd.grad, gr.grad, 4e-3); check(tag + " dbeta", bd.grad, br.grad, 4e-3)
+    if mode == 2:
+        check(tag + " dres", rd.grad.float(), rr.grad, 4e-3)
+    for k in sd:
+        check(tag + " d" + k, ps[k].grad, sdr[k].grad, 1e-2)
