@@ -132,6 +132,18 @@ int mgvae_conv2d_nhwc_bf16_fwd(const MgvaeConvDesc* d, const void* x, const void
 int mgvae_conv2d_nhwc_bf16_bwd_data(const MgvaeConvDesc* d, const void* y, const void* wt, const float* bias, void* x,
                                     const MgvaeActMask* mask, void* stream);
 int mgvae_conv2d_nhwc_bf16_bwd_weight(const MgvaeConvDesc* d, const void* x, const void* y, float* dw, void* stream);
+/* fp32-STORAGE forms on the bf16 matrix pipe ("x3", csrc/conv_nhwc_x3.inc): same tensors and results as the fp32 entry
+ * points above (x / y / dw fp32, fp32 accumulation), but every fp32 operand value enters the matrix pipe as the exact sum
+ * of three bf16 values and each product as six bf16 MFMAs (relative error < 2^-22 per product: fp32 grade) -- 16 / 6 of
+ * the fp32 MFMA rate.  Activations are split while staged; weights once per optimizer step by mgvae_pack_conv_weights_x3
+ * into wk3 [3, Cy, KH*KW, Cx] (forward) and wt3 [3, Cx, KH*KW, Cy] (data gradient / transposed-conv forward), bf16.
+ * Channel counts multiples of 16, slice offsets multiples of 4.                                                         */
+int mgvae_pack_conv_weights_x3(const float* w, void* wk3, void* wt3, int Cy, int T, int Cx, void* stream);
+int mgvae_conv2d_nhwc_x3_fwd(const MgvaeConvDesc* d, const float* x, const void* wk3, const float* bias, float* y,
+                             const MgvaeActMask* mask, void* stream);
+int mgvae_conv2d_nhwc_x3_bwd_data(const MgvaeConvDesc* d, const float* y, const void* wt3, const float* bias, float* x,
+                                  const MgvaeActMask* mask, void* stream);
+int mgvae_conv2d_nhwc_x3_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw, void* stream);
 
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,
                             void* stream);
@@ -224,8 +236,9 @@ int mgvae_norm_cbam_nhwc_bwd(const void* x, const float* gamma, const float* bet
                              void* dres, float* dgamma, float* dbeta, float* dw1, float* dw2, float* dwsp,
                              float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff, int mode, int act,
                              float slope, int storage, void* stream);
-/* InstanceNorm2d (+ReLU / LeakyReLU) alone on channels-last tensors (graph/decoder.py:81-83,124-126); `stats`: 6 N C
- * floats kept for backward, `scratch`: 2 N C floats; and the bias gradient of a transposed conv (sum over pixel rows).   */
+/* InstanceNorm2d (+ReLU / LeakyReLU) alone on channels-last tensors (graph/decoder.py:81-83,124-126); `stats`:
+ * mgvae_instance_norm_nhwc_stats_floats() floats (6 N C kept for backward + the chunked statistics pass's partials), `scratch`: 2 N C floats; and the bias gradient of a transposed conv (sum over pixel rows).   */
+size_t mgvae_instance_norm_nhwc_stats_floats(int N, int C, int H, int W);   /* floats of the `stats` workspace below */
 int mgvae_instance_norm_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int N,
                                  int C, int H, int W, int y_ctot, int y_coff, float eps, int act, float slope, int storage,
                                  void* stream);
@@ -330,9 +343,10 @@ int mgvae_bf16_rows_sum(const void* rows_bf16, void* dst_bf16, int R, size_t n, 
  * {kind (0 fwd,1 bwd_data,2 bwd_weight igemm; 3 fwd,4 bwd_data direct), tile id, launches, total ms, total flops}.
  * Kinds 5..7 are the HBM-bound kernels (flat Adam, InstanceNorm forward / backward): their `flops` field carries the
  * ALGORITHMIC BYTES of the launch instead (Adam 7 x 4n; InstanceNorm 2 x / 3 x 4 N C P).
- * Kinds 8..10: the channels-last implicit-GEMM kernels (forward, data gradient, weight gradient); 11..13: their bf16 forms. */
+ * Kinds 8..10: the channels-last implicit-GEMM kernels (forward, data gradient, weight gradient); 11..13: their bf16-storage
+ * forms; 14..16: their fp32-storage forms on the bf16 matrix pipe (x3). */
 enum { MGVAE_PROF_ADAM = 5, MGVAE_PROF_INORM_FWD = 6, MGVAE_PROF_INORM_BWD = 7, MGVAE_PROF_NHWC_FWD = 8, MGVAE_PROF_NHWC_BF16_FWD = 11,
-       MGVAE_PROF_KINDS = 14 };
+       MGVAE_PROF_NHWC_X3_FWD = 14, MGVAE_PROF_KINDS = 17 };
 typedef struct MgvaeProfRec { int32_t kind, tile, launches; double ms, flops; } MgvaeProfRec;
 int mgvae_prof_enable(int on);
 int mgvae_prof_collect(MgvaeProfRec* out, int cap);

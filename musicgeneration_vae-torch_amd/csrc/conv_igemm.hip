@@ -1901,10 +1901,11 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
     static char buf[5][7][48];
-    static char nbuf[6][7][48];
-    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 6 && tile >= 0 && tile < 4) {
+    static char nbuf[9][7][48];
+    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 9 && tile >= 0 && tile < 4) {
         const int m = kind - MGVAE_PROF_NHWC_FWD;
-        snprintf(nbuf[m][tile], 48, m < 3 ? "nhwc_igemm_kernel<%d, %s>" : "nhwc_igemm_bf16_kernel<%d, %s>", m % 3, tiles[tile]);
+        static const char* fam[3] = {"nhwc_igemm_kernel<%d, %s>", "nhwc_igemm_bf16_kernel<%d, %s>", "nhwc_igemm_x3_kernel<%d, %s>"};
+        snprintf(nbuf[m][tile], 48, fam[m / 3], m % 3, tiles[tile]);
         return nbuf[m][tile];
     }
     if (kind == MGVAE_PROF_ADAM) return "adam_kernel";
@@ -1945,3 +1946,4 @@ extern "C" const char* mgvae_strerror(int code) {
 
 #include "conv_nhwc.inc"
 #include "conv_nhwc_bf16.inc"
+#include "conv_nhwc_x3.inc"

@@ -53,6 +53,10 @@ SIGNATURES = {
     "mgvae_conv2d_nhwc_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_bf16_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_bf16_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
+    "mgvae_pack_conv_weights_x3": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "mgvae_conv2d_nhwc_x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_x3_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_x3_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),
     "mgvae_conv2d_fwd_packed": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P]),
@@ -72,6 +76,7 @@ SIGNATURES = {
     "mgvae_norm_cbam_nhwc_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_norm_cbam_nhwc_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_int, c_float, c_int, P]),
     "mgvae_norm_cbam_nhwc_bwd": (c_int, [P] * 17 + [c_int] * 8 + [c_float, c_int, P]),
+    "mgvae_instance_norm_nhwc_stats_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_instance_norm_nhwc_fwd": (c_int, [P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_float, c_int, P]),
     "mgvae_instance_norm_nhwc_bwd": (c_int, [P] * 9 + [c_int] * 7 + [c_float, c_int, P]),
     "mgvae_channel_sum_nhwc_accum": (c_int, [P, ctypes.c_long, c_int, c_int, c_int, P, c_int, P]),

@@ -99,7 +99,7 @@ def _direct_candidate(d):
     fp32 operands (True tries it wherever the geometry is supported)"""
     if USE_DIRECT is True:
         return True
-    return d.KH * d.KW >= 9 and d.OH * d.OW >= 128 and d.H * d.W >= 128 and get_compute_dtype() == "f32"
+    return d.KH * d.KW >= 9 and d.OH * d.OW >= 128 and d.H * d.W >= 128 and get_nchw_operand_dtype() == "f32"
 
 
 def _direct_wins(mode, d, run_igemm, run_direct):
@@ -132,14 +132,35 @@ def _mask(t, act, slope):
     return nat.ActMask(t.data_ptr(), ct, 0, act, slope), t
 
 
+_compute_dtype = ["f32"]
+
+
 def set_compute_dtype(name):
-    """"f32" (default) or "bf16": matrix-operand precision of the tiled conv kernels (mgvae_set_compute_dtype):
-    bf16 = BASELINE.json configs 3-4, bf16 operands / fp32 accumulate / fp32 tensors and master weights"""
-    code = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "f32_bf16x3": 2}[str(name).lower()]
-    nat.check(nat.lib().mgvae_set_compute_dtype(code), "set_compute_dtype")
+    """"f32" (default) or "bf16" (BASELINE.json configs 3-4).  bf16 = the channels-last island -- the encoder trunks and
+    the decoder's blocks, 97 % of the step's FLOPs -- keeps activations and their gradients as bf16 tensors and multiplies
+    bf16 copies of the fp32 master weights on the bf16 matrix pipe (fp32 accumulation, statistics, gates, weight gradients
+    and Adam); everything outside the island (C = 1 / C = 32 stems, the latent linears, the output convs, the
+    discriminators) stays fp32.  One rounding model, independent of which kernel variant the tuner picks: it is the one
+    oracle.restate.ISLAND_ROUNDING restates and tests/test_hip_parity.py checks the bf16 step against."""
+    name = {"fp32": "f32", "float32": "f32", "bfloat16": "bf16"}.get(str(name).lower(), str(name).lower())
+    if name not in ("f32", "bf16"):
+        raise ValueError("compute dtype must be f32 or bf16, got %r" % (name,))
+    _compute_dtype[0] = name
 
 
 def get_compute_dtype():
+    return _compute_dtype[0]
+
+
+def set_nchw_operand_dtype(name):
+    """operand precision of the NCHW tiled conv kernels alone (mgvae_set_compute_dtype): "f32", "bf16" (operands rounded to
+    bf16 while staged, fp32 accumulation) or "f32_bf16x3".  Not used by any model path; the kernels are kept and tested
+    (tests/test_hip_parity.py::test_conv2d_bf16_compute)."""
+    code = {"f32": 0, "bf16": 1, "f32_bf16x3": 2}[str(name).lower()]
+    nat.check(nat.lib().mgvae_set_compute_dtype(code), "set_compute_dtype")
+
+
+def get_nchw_operand_dtype():
     return {0: "f32", 1: "bf16", 2: "f32_bf16x3"}[nat.lib().mgvae_get_compute_dtype()]
 
 
@@ -1162,6 +1183,38 @@ def _bf16_weights(w):
     return c[1], c[2]
 
 
+# fp32 islands: which matrix instruction multiplies.  "x3" (default): csrc/conv_nhwc_x3.inc -- every fp32 operand enters the
+# bf16 matrix pipe as the exact sum of three bf16 values, every product as six bf16 MFMAs (fp32-grade: relative error
+# < 2^-22 per product, fp32 accumulation; tests/test_nhwc_gpu.py holds it to twice the fp32 instruction's own error);
+# "mfma32": csrc/conv_nhwc.inc on v_mfma_f32_32x32x2_f32.  Same tensors, same results to fp32 rounding.
+FP32_ENGINE = _os.environ.get("MGVAE_FP32_ENGINE", "x3")
+if FP32_ENGINE not in ("x3", "mfma32"):
+    raise RuntimeError("MGVAE_FP32_ENGINE must be x3 or mfma32, got %r" % FP32_ENGINE)
+
+
+def _x3_ok(cx, cy):
+    return FP32_ENGINE == "x3" and cx % 16 == 0 and cy % 16 == 0
+
+
+def _x3_weights(w):
+    """(wk3, wt3): the fp32 channels-last master weight as three bf16 planes each way -- wk3 [3, Cy, T, Cx] for the forward
+    product, wt3 [3, Cx, T, Cy] for the data gradient -- re-split once per optimizer step (see _bf16_weights)."""
+    owner = getattr(w, "_mg_owner", None)
+    ver = (owner.weights_version[0] if owner is not None else -1, w._version, w.data_ptr())
+    c = getattr(w, "_mg_x3", None)
+    if c is None or c[0] != ver or torch.cuda.is_current_stream_capturing():
+        cy, cx, kh, kw = w.shape
+        if c is None:
+            wk = torch.empty(3 * w.numel(), device=w.device, dtype=torch.bfloat16)
+            wt = torch.empty(3 * w.numel(), device=w.device, dtype=torch.bfloat16)
+        else:
+            wk, wt = c[1], c[2]
+        nat.check(nat.lib().mgvae_pack_conv_weights_x3(_p(w), _p(wk), _p(wt), cy, kh * kw, cx, _s()), "pack_conv_weights_x3")
+        c = (ver, wk, wt)
+        w._mg_x3 = c
+    return c[1], c[2]
+
+
 class _ToChannelsLastFn(torch.autograd.Function):
     """NCHW fp32 (dense or a channel slice) -> dense channels-last copy of the island's storage type; backward converts the
     gradient back to NCHW fp32"""
@@ -1239,6 +1292,9 @@ class _ConvClFn(torch.autograd.Function):
         if x.dtype == torch.bfloat16:
             wk, _ = _bf16_weights(w)
             nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), _p(x), _p(wk), _p(b), _p(y), None, _s()), "conv2d_nhwc_bf16_fwd")
+        elif _x3_ok(Cx, Cy):
+            wk3, _ = _x3_weights(w)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), _p(x), _p(wk3), _p(b), _p(y), None, _s()), "conv2d_nhwc_x3_fwd")
         else:
             nat.check(nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "conv2d_nhwc_fwd")
         ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
@@ -1266,7 +1322,7 @@ class _ConvClFn(torch.autograd.Function):
 
         def weight_grads():
             if w.requires_grad:
-                fn = L.mgvae_conv2d_nhwc_bf16_bwd_weight if bf else L.mgvae_conv2d_nhwc_bwd_weight
+                fn = L.mgvae_conv2d_nhwc_bf16_bwd_weight if bf else (L.mgvae_conv2d_nhwc_x3_bwd_weight if _x3_ok(Cx, Cy) else L.mgvae_conv2d_nhwc_bwd_weight)
                 nat.check(fn(ctypes.byref(d), _p(x), _p(dy), _p(grad_slot(w)), _s()), "conv2d_nhwc_bwd_weight")
             if b is not None and b.requires_grad:
                 nat.check(L.mgvae_channel_sum_nhwc_accum(_p(dy), N * OH * OW, Cy, dct, 0, _p(grad_slot(b)), _store(dy), _s()), "bias_grad_nhwc")
@@ -1288,6 +1344,9 @@ class _ConvClFn(torch.autograd.Function):
             if bf:
                 _, wt = _bf16_weights(w)
                 nat.check(L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d2), _p(dy), _p(wt), None, _p(dx), mref, _s()), "conv2d_nhwc_bf16_bwd_data")
+            elif _x3_ok(Cx, Cy):
+                _, wt3 = _x3_weights(w)
+                nat.check(L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d2), _p(dy), _p(wt3), None, _p(dx), mref, _s()), "conv2d_nhwc_x3_bwd_data")
             else:
                 nat.check(L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), mref, _s()), "conv2d_nhwc_bwd_data")
         return dx, None, None, None, None, None, None, None, None, None
@@ -1401,7 +1460,7 @@ class _InstNormClFn(torch.autograd.Function):
             raise RuntimeError("instance_norm (channels-last): the normalised tensor must be dense")
         y = out if out is not None else new_channels_last(N, C, H, W, x.device, x.dtype)
         yct = _need_cl(y, "instance_norm output")
-        stats = torch.empty((6 * N * C,), device=x.device, dtype=torch.float32)
+        stats = torch.empty((nat.lib().mgvae_instance_norm_nhwc_stats_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
         nat.check(nat.lib().mgvae_instance_norm_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), N, C, H, W, yct, 0, eps, act,
                                                          slope, _store(x), _s()), "instance_norm_nhwc_fwd")
         ctx.save_for_backward(x, gamma, stats, y)
@@ -1452,6 +1511,9 @@ class _ConvTClFn(torch.autograd.Function):
         if x.dtype == torch.bfloat16:
             _, wt = _bf16_weights(w)
             nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), _p(x), _p(wt), _p(b), _p(y), None, _s()), "convT_nhwc_bf16_fwd")
+        elif _x3_ok(Co, Ci):
+            _, wt3 = _x3_weights(w)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), _p(x), _p(wt3), _p(b), _p(y), None, _s()), "convT_nhwc_x3_fwd")
         else:
             nat.check(nat.lib().mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "convT_nhwc_fwd")
         ctx.geom = (N, Co, OH, OW, Ci, h, wd, k, stride, pad, xct, act, slope)
@@ -1476,7 +1538,7 @@ class _ConvTClFn(torch.autograd.Function):
         def weight_grads():
             if w.requires_grad:
                 d = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, xct, ACT_NONE, 0.0)
-                fn = L.mgvae_conv2d_nhwc_bf16_bwd_weight if bf else L.mgvae_conv2d_nhwc_bwd_weight
+                fn = L.mgvae_conv2d_nhwc_bf16_bwd_weight if bf else (L.mgvae_conv2d_nhwc_x3_bwd_weight if _x3_ok(Co, Ci) else L.mgvae_conv2d_nhwc_bwd_weight)
                 nat.check(fn(ctypes.byref(d), _p(dy), _p(x), _p(grad_slot(w)), _s()), "convT_nhwc_bwd_weight")
             if b is not None and b.requires_grad:
                 nat.check(L.mgvae_channel_sum_nhwc_accum(_p(dy), N * OH * OW, Co, dct, 0, _p(grad_slot(b)), _store(dy), _s()), "bias_grad_nhwc")
@@ -1494,6 +1556,9 @@ class _ConvTClFn(torch.autograd.Function):
             if bf:
                 wk, _ = _bf16_weights(w)
                 nat.check(L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d2), _p(dy), _p(wk), None, _p(dx), None, _s()), "convT_nhwc_bf16_bwd_data")
+            elif _x3_ok(Co, Ci):
+                wk3, _ = _x3_weights(w)
+                nat.check(L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d2), _p(dy), _p(wk3), None, _p(dx), None, _s()), "convT_nhwc_x3_bwd_data")
             else:
                 nat.check(L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), None, _s()), "convT_nhwc_bwd_data")
         return dx, None, None, None, None, None, None, None, None

@@ -13,6 +13,22 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+# Test hook for the bf16-STORAGE mode (BASELINE.json configs 3-4; tests/test_hip_parity.py's bf16 step): a pair of callables
+# (round_activation, round_weight).  When set, every convolution of the encoder trunks and of the decoder's blocks / fit1
+# -- the channels-last island, where the HIP path keeps activations and their gradients as bf16 tensors and multiplies
+# bf16 copies of the fp32 master weights -- sees rounded operands and stores a rounded result:
+#     y = round_activation(conv(round_activation(x), round_weight(w)))
+# None (the default, and the only state the golden vectors / CPU baseline ever see): plain arithmetic.
+ISLAND_ROUNDING = None
+
+
+def _island(fn, x, w, *a, **k):
+    if ISLAND_ROUNDING is None:
+        return fn(x, w, *a, **k)
+    qa, qw = ISLAND_ROUNDING
+    return qa(fn(qa(x), qw(w), *a, **k))
+
+
 ENC_LAYERS = (64, 128, 256, 512, 1024)
 DEC_LAYERS = (1024, 512, 256, 128, 64)
 Z_DIM = 1152
@@ -67,8 +83,8 @@ def enc_pitch_time(sd, p, x):
 
 def residual_module(sd, p, x):
     """graph/encodingBlock.py:87-100"""
-    o = F.relu(F.conv2d(x, sd[p + "conv1.weight"], padding=1))
-    o = F.conv2d(o, sd[p + "conv2.weight"], padding=1)
+    o = F.relu(_island(F.conv2d, x, sd[p + "conv1.weight"], padding=1))
+    o = _island(F.conv2d, o, sd[p + "conv2.weight"], padding=1)
     o = instance_norm(sd, p + "bn.", o)
     o = cbam(sd, p + "cbam.", o)
     return F.relu(x + o)
@@ -76,7 +92,7 @@ def residual_module(sd, p, x):
 
 def pooling_module(sd, p, x):
     """graph/encodingBlock.py:118-126"""
-    o = F.conv2d(x, sd[p + "conv.weight"], stride=2, padding=1)
+    o = _island(F.conv2d, x, sd[p + "conv.weight"], stride=2, padding=1)
     o = instance_norm(sd, p + "bn.", o)
     o = o + cbam(sd, p + "cbam.", o)
     return F.relu(o)
@@ -138,26 +154,26 @@ def dec_time_pitch(sd, p, x):
 
 def deconv_pitch_padding(sd, p, x):
     """graph/decoder.py:135-154 (bn2 on both branches, bn1 unused: defect D5)"""
-    o1 = F.conv_transpose2d(x, sd[p + "deConv1.weight"], sd[p + "deConv1.bias"], stride=2, padding=1,
+    o1 = _island(F.conv_transpose2d, x, sd[p + "deConv1.weight"], sd[p + "deConv1.bias"], stride=2, padding=1,
                             output_padding=(0, 1))
     o1 = instance_norm(sd, p + "bn2.", o1)
     o1 = F.relu(o1 + cbam(sd, p + "cbam1.", o1))
-    o2 = F.conv_transpose2d(x, sd[p + "deConv2.weight"], sd[p + "deConv2.bias"], stride=2, padding=1,
+    o2 = _island(F.conv_transpose2d, x, sd[p + "deConv2.weight"], sd[p + "deConv2.bias"], stride=2, padding=1,
                             output_padding=(0, 1))
     o2 = F.relu(instance_norm(sd, p + "bn2.", o2))
-    o = F.conv2d(torch.cat((o1, o2), dim=1), sd[p + "conv.weight"])
+    o = _island(F.conv2d, torch.cat((o1, o2), dim=1), sd[p + "conv.weight"])
     o = instance_norm(sd, p + "bn3.", o)
     return F.relu(o + cbam(sd, p + "cbam2.", o))
 
 
 def deconv_module(sd, p, x):
     """graph/decoder.py:91-109"""
-    o1 = F.conv_transpose2d(x, sd[p + "deConv1.weight"], stride=2, padding=1)
+    o1 = _island(F.conv_transpose2d, x, sd[p + "deConv1.weight"], stride=2, padding=1)
     o1 = F.relu(instance_norm(sd, p + "bn1.", o1))
-    o2 = F.conv_transpose2d(x, sd[p + "deConv2.weight"], sd[p + "deConv2.bias"], stride=2, padding=1,
+    o2 = _island(F.conv_transpose2d, x, sd[p + "deConv2.weight"], sd[p + "deConv2.bias"], stride=2, padding=1,
                             output_padding=1)
     o2 = F.relu(instance_norm(sd, p + "bn2.", o2))
-    o = F.conv2d(torch.cat((o1, o2), dim=1), sd[p + "conv.weight"])
+    o = _island(F.conv2d, torch.cat((o1, o2), dim=1), sd[p + "conv.weight"])
     o = instance_norm(sd, p + "bn3.", o)
     return F.relu(o + cbam(sd, p + "cbam.", o))
 
@@ -182,7 +198,7 @@ def decoder(sd, p, z, pre_z, phrase_feature, position, train=False, drop_masks=N
     if taps is not None:
         taps[p + "pitch"] = pitch
         taps[p + "time"] = time
-    o = F.conv2d(torch.cat((pitch, time), dim=1), sd[p + "fit1.weight"])
+    o = _island(F.conv2d, torch.cat((pitch, time), dim=1), sd[p + "fit1.weight"])
     o = instance_norm(sd, p + "bn.", o)
     o = F.relu(o + cbam(sd, p + "cbam.", o))
     if taps is not None:

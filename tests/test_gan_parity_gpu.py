@@ -175,8 +175,11 @@ def _compare_net(tag, module, hip_grads, oracle_grads, ref32_grads, osd, sd0, lr
         if g.abs().max().item() <= 1e-6 * gs:
             continue
         check_grad("%s d%s" % (tag, n), hip_grads[n], g, 2 * TOL, atol=1e-6 * gs, ref32=ref32_grads[n])
-        # first Adam step: dw = -lr * g / (|g| + eps) -> compare where the gradient is clear of the noise floor
-        big = g.abs() > 1e-3 * g.abs().max()
+        # first Adam step: dw = -lr * g / (|g| + eps) -> compare where the gradient is clear of the noise floor: 1e-3 of the
+        # tensor's largest entry, or ten times the gradient error just measured when the row passed through a relaxed rule
+        big = g.abs() > max(1e-3, 10 * check_grad.last_rel) * g.abs().max()
+        if not big.any():
+            continue
         dw_h = (named[n].detach().cpu().double() - sd0[n].double())[big]
         dw_o = (osd[n].detach() - sd0[n].double())[big]
         bad = ((dw_h - dw_o).abs() > 0.02 * lr).double().mean().item()

@@ -832,7 +832,7 @@ BF16_GEOMS = [
 
 @pytest.mark.parametrize("g", BF16_GEOMS, ids=lambda g: "x".join(map(str, g[:5])) + "k%dx%d" % g[5])
 def test_conv2d_bf16_compute(g):
-    """bf16-compute mode (configs 3-4): operands rounded to bf16 (RNE), fp32 accumulation.  The reference rounds the
+    """the NCHW kernels' bf16-operand mode (set_nchw_operand_dtype; no model path uses it): operands rounded to bf16 (RNE), fp32 accumulation.  The reference rounds the
     same operands to bf16 and multiplies in fp64, so what remains is fp32 accumulation error: the fp32 tolerance."""
     N, Ci, H, W_, Co, k, s, p = g
     hf = HF()
@@ -843,7 +843,7 @@ def test_conv2d_bf16_compute(g):
     dy = torch.randn_like(yr).bfloat16().double()          # exactly representable: both gradients see the same dy
     want_dx = torch.nn.grad.conv2d_input(xr.shape, wr.detach(), dy, s, p)
     want_dw = torch.nn.grad.conv2d_weight(xr.detach(), wr.shape, dy, s, p)
-    hf.set_compute_dtype("bf16")
+    hf.set_nchw_operand_dtype("bf16")
     try:
         xd = x.to(dev).requires_grad_(True); wd = torch.nn.Parameter(w.to(dev))
         y = hf.conv2d(xd, wd, None, s, p)
@@ -857,15 +857,15 @@ def test_conv2d_bf16_compute(g):
         z = hf.conv_transpose2d(x.to(dev), wt.to(dev), None, s, p)
         check("bf16 convT fwd %s" % (g,), z, zr)
     finally:
-        hf.set_compute_dtype("f32")
-    assert hf.get_compute_dtype() == "f32"
+        hf.set_nchw_operand_dtype("f32")
+    assert hf.get_nchw_operand_dtype() == "f32"
 
 
 def test_train_step_bf16_close_to_fp32():
-    """one generator pre-training step in bf16-compute mode against the same step in fp32 (well-conditioned weights):
-    loss within 1 %; the flat gradient points the same way (cosine > 0.93, relative L2 < 0.4: bf16 operands carry
-    2^-9 relative rounding per layer, and ReLU / arg-max decisions near ties flip through ~40 layers -- measured 0.13).
-    The kernels themselves are pinned at fp32 tolerance against a bf16-rounded reference in test_conv2d_bf16_compute."""
+    """one generator pre-training step with the bf16-storage island against the same step in fp32 (well-conditioned
+    weights): a sanity bound, not the parity test (that is test_bf16_storage_step_against_bf16_rounding_oracle): loss
+    within 3 %; the flat gradient points the same way (cosine > 0.93, relative L2 < 0.4: every stored activation carries
+    2^-9 relative rounding, twice per layer, and ReLU / arg-max decisions near ties flip through ~40 layers)."""
     import __graft_entry__ as ge
     ge.build()
     from graph.model import Model
@@ -901,10 +901,111 @@ def test_train_step_bf16_close_to_fp32():
             grads[mode] = step.opt.grad.detach().double().cpu().clone()
         finally:
             hf.set_compute_dtype("f32")
-    assert abs(losses["bf16"] - losses["f32"]) <= 1e-2 * abs(losses["f32"]), losses
+    assert abs(losses["bf16"] - losses["f32"]) <= 3e-2 * abs(losses["f32"]), losses
     rel = float((grads["bf16"] - grads["f32"]).norm() / grads["f32"].norm())
     cos = float((grads["bf16"] * grads["f32"]).sum() / (grads["bf16"].norm() * grads["f32"].norm()))
     assert rel < 0.4 and cos > 0.93, (rel, cos)
+
+
+class _RoundBf16(torch.autograd.Function):
+    """what a bf16-stored tensor is: rounded (RNE) on the way forward AND its gradient rounded on the way back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundBf16Forward(torch.autograd.Function):
+    """a bf16 COPY of an fp32 master weight: rounded forward, its gradient stays fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def test_bf16_storage_step_against_bf16_rounding_oracle():
+    """BASELINE.json configs 3-4 (bf16): one pre-training step at 32 bars with the channels-last island in bf16 STORAGE
+    against the oracle run in fp64 with the SAME rounding model -- every island convolution sees bf16-rounded activations
+    and bf16 copies of the fp32 master weights, stores a bf16 result, and receives a bf16-rounded gradient
+    (oracle.restate.ISLAND_ROUNDING).  What that model does not cover (the bf16 stores of the fused norm/CBAM outputs are
+    the next conv's rounding, but its residual branch and the gradients inside the fused backward are rounded once more) is
+    the same size as what it covers, so the bar is relative: the HIP step must be as close to the rounding oracle as the
+    rounding oracle is to exact arithmetic (x 1.5), tensor by tensor on the large tensors and on the flat gradient, and
+    closer to the rounding oracle than to exact arithmetic's opposite side (cosine)."""
+    from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
+    from graph.loss.bar_loss import Loss, DLoss
+    from hipops import FlatParams
+    hf = HF()
+    mode, B = "wc", 32
+    zsd = W.make_state_dict(W.manifest_z_discriminator(), 0, mode)
+    note, pre, phrase, pos = W.make_inputs(B, seed=977)
+    hf.set_compute_dtype("bf16")
+    try:
+        m, gsd = _generator(mode)
+        zb, zp = BarZDiscriminator(), PhraseZDiscriminator()
+        zb.load_state_dict(zsd); zp.load_state_dict(zsd)
+        zb, zp = zb.to(dev), zp.to(dev)
+        for d in (zb, zp):
+            for prm in d.parameters():
+                prm.requires_grad = False
+        opt = FlatParams(list(m.parameters()), lr=0.002)
+        opt.zero_grad()
+        n_, p_, ph_, po_ = (t.to(dev) for t in (note, pre, phrase, pos))
+        gen, z, pz, pf = m(n_, p_, ph_, po_)
+        loss = DLoss.constant(zp(pf).view(-1), 1.0) + DLoss.constant(zb(z).view(-1), 1.0) + DLoss.constant(zb(pz).view(-1), 1.0)
+        loss = loss + Loss().to(dev)(gen, n_, True)
+        loss.backward()
+        torch.cuda.synchronize()
+        params = dict(m.named_parameters())
+        hip = {n: p.grad.detach().double().cpu() for n, p in params.items() if p.grad is not None}
+        hip_loss = float(loss.detach())
+    finally:
+        hf.set_compute_dtype("f32")
+    names = [n for n in params if n in gsd]
+    z64 = {k: v.double() for k, v in zsd.items()}
+
+    def oracle(rounding):
+        osd = {k: v.clone().double().requires_grad_(True) for k, v in gsd.items()}
+        R.ISLAND_ROUNDING = rounding
+        try:
+            lo, _ = R.pretrain_step_loss(osd, z64, z64, note.double(), pre.double(), phrase.double(), pos, True)
+            og = torch.autograd.grad(lo, [osd[n] for n in names], allow_unused=True)
+        finally:
+            R.ISLAND_ROUNDING = None
+        return float(lo.detach()), dict(zip(names, og))
+
+    lo_r, g_r = oracle((_RoundBf16.apply, _RoundBf16Forward.apply))
+    lo_x, g_x = oracle(None)
+    REPORT.append("bf16 step (32 bars): loss hip %.6f  rounding oracle %.6f  exact %.6f" % (hip_loss, lo_r, lo_x))
+    assert abs(hip_loss - lo_r) <= max(2 * abs(lo_r - lo_x), 2e-3 * abs(lo_x)), (hip_loss, lo_r, lo_x)
+    keep = [n for n in names if g_x[n] is not None and n in hip]
+    flat = lambda d: torch.cat([d[n].reshape(-1).double() for n in keep])
+    fh, fr, fx = flat(hip), flat(g_r), flat(g_x)
+    e_hip = float((fh - fr).norm() / fr.norm()); e_model = float((fr - fx).norm() / fx.norm()); e_exact = float((fh - fx).norm() / fx.norm())
+    cos = float((fh * fr).sum() / (fh.norm() * fr.norm()))
+    REPORT.append("bf16 step: flat gradient  |hip - rounding oracle| %.3e   |rounding oracle - exact| %.3e   |hip - exact| %.3e   cos(hip, rounding oracle) %.5f"
+                  % (e_hip, e_model, e_exact, cos))
+    worst = []
+    for n in keep:
+        if g_x[n].numel() < 4096:
+            continue                                   # small aggregates: covered by the flat vector
+        a = float((hip[n] - g_r[n]).norm() / g_r[n].norm().clamp_min(1e-300))
+        b = float((g_r[n] - g_x[n]).norm() / g_x[n].norm().clamp_min(1e-300))
+        worst.append((a / max(b, 1e-3), n, a, b))
+    worst.sort(reverse=True)
+    for ratio, n, a, b in worst[:8]:
+        REPORT.append("    %-60s |hip - rounding oracle| %.3e   |rounding oracle - exact| %.3e   ratio %.2f" % (n, a, b, ratio))
+    assert e_hip <= 1.5 * max(e_model, 2e-3), (e_hip, e_model)
+    assert cos >= 1.0 - 2.0 * max(e_model, 2e-3) ** 2, cos
+    assert worst[0][0] <= 3.0, worst[0]
 
 
 def test_graphed_train_step_matches_eager():
@@ -977,7 +1078,7 @@ def test_conv2d_f32_via_bf16x3(g):
     yr.backward(dy)
     errs = {}
     for mode in ("f32", "f32_bf16x3"):
-        hf.set_compute_dtype(mode)
+        hf.set_nchw_operand_dtype(mode)
         try:
             xd = x.to(dev).requires_grad_(True); wd = torch.nn.Parameter(w.to(dev))
             y = hf.conv2d(xd, wd, None, s, p)
@@ -989,7 +1090,7 @@ def test_conv2d_f32_via_bf16x3(g):
                 check("f32 via bf16x3 dx %s" % (g,), xd.grad, xr.grad)
                 check("f32 via bf16x3 dw %s" % (g,), wd.grad, wr.grad)
         finally:
-            hf.set_compute_dtype("f32")
+            hf.set_nchw_operand_dtype("f32")
     # fp32 accuracy, not bf16 accuracy: within a small factor of the native kernel's own error (both ~1e-7..1e-6)
     for e_split, e_native in zip(errs["f32_bf16x3"], errs["f32"]):
         assert e_split <= max(4 * e_native, 2e-6), (errs, g)
