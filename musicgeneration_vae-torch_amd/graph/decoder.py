@@ -14,10 +14,11 @@ from graph.layers import Conv2d, ConvTranspose2d, Embedding, InstanceNorm2d, Lin
 from graph.weights_initializer import weights_init
 
 
-def _new(channels_last, n, c, h, w, device):
+def _new(channels_last, n, c, h, w, like):
+    """the buffer two branches are written into side by side: same layout AND storage type (fp32 / bf16 island) as ``like``"""
     if channels_last:
-        return HF.new_channels_last(n, c, h, w, device)
-    return torch.empty((n, c, h, w), device=device, dtype=torch.float32)
+        return HF.new_channels_last(n, c, h, w, like.device, like.dtype)
+    return torch.empty((n, c, h, w), device=like.device, dtype=torch.float32)
 
 
 class _Stem(nn.Module):
@@ -69,7 +70,7 @@ class DeConvModule(nn.Module):
     def forward(self, x, out=None):
         co = self.out_channel
         n, _, h, w = x.shape
-        cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w, x.device)
+        cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w, x)
         with HF.forked_branch(x, cat):            # the two transposed-conv branches are independent until the cat
             b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.bn1(self.deConv1(x), act=HF.ACT_RELU, out=cat[:, :co])
@@ -99,7 +100,7 @@ class DeConvPitchPadding(nn.Module):
     def forward(self, x, out=None):
         co = self.out_channel
         n, _, h, w = x.shape
-        cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w + 1, x.device)
+        cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w + 1, x)
         with HF.forked_branch(x, cat):
             b = self.bn2(self.deConv2(x), act=HF.ACT_RELU, out=cat[:, co:])
         a = self.cbam1.fused_norm(self.deConv1(x), self.bn2, 1, act=HF.ACT_RELU, out=cat[:, :co], channels_last=self.channels_last)

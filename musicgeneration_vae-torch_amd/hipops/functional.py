@@ -1151,6 +1151,11 @@ def _need_cl(t, what):
     return ct
 
 
+def _same_storage(x, y, what):
+    if x.dtype != y.dtype:
+        raise RuntimeError("%s: input is stored as %s but the output buffer as %s" % (what, x.dtype, y.dtype))
+
+
 def _cl_weight(w, what):
     co, ci, kh, kw = w.shape
     if w.stride() != (kh * kw * ci, 1, kw * ci, ci) and not (kh == 1 and kw == 1 and w.stride(0) == ci and w.stride(1) == 1):
@@ -1288,6 +1293,7 @@ class _ConvClFn(torch.autograd.Function):
         OW = (W + 2 * pad[1] - KW) // stride[1] + 1
         y = out if out is not None else new_channels_last(N, Cy, OH, OW, x.device, x.dtype)
         yct = _need_cl(y, "conv2d (channels-last) output")
+        _same_storage(x, y, "conv2d (channels-last)")
         d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
         if x.dtype == torch.bfloat16:
             wk, _ = _bf16_weights(w)
@@ -1386,6 +1392,7 @@ class _NormCbamClFn(torch.autograd.Function):
         L = nat.lib()
         y = out if out is not None else new_channels_last(N, C, H, W, x.device, x.dtype)
         yct = _need_cl(y, "norm_cbam output")
+        _same_storage(x, y, "norm_cbam (channels-last)")
         save = torch.empty((L.mgvae_norm_cbam_nhwc_save_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
         nat.check(L.mgvae_norm_cbam_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(res), rct, 0, _p(w1), _p(w2), _p(wsp), _p(y), _p(save),
                                              N, C, H, W, yct, 0, eps, mode, act, slope, _store(x), _s()), "norm_cbam_nhwc_fwd")
@@ -1460,6 +1467,7 @@ class _InstNormClFn(torch.autograd.Function):
             raise RuntimeError("instance_norm (channels-last): the normalised tensor must be dense")
         y = out if out is not None else new_channels_last(N, C, H, W, x.device, x.dtype)
         yct = _need_cl(y, "instance_norm output")
+        _same_storage(x, y, "instance_norm (channels-last)")
         stats = torch.empty((nat.lib().mgvae_instance_norm_nhwc_stats_floats(N, C, H, W),), device=x.device, dtype=torch.float32)
         nat.check(nat.lib().mgvae_instance_norm_nhwc_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), N, C, H, W, yct, 0, eps, act,
                                                          slope, _store(x), _s()), "instance_norm_nhwc_fwd")
@@ -1505,6 +1513,7 @@ class _ConvTClFn(torch.autograd.Function):
         OW = (wd - 1) * stride[1] - 2 * pad[1] + KW + opad[1]
         y = out if out is not None else new_channels_last(N, Co, OH, OW, x.device, x.dtype)
         yct = _need_cl(y, "conv_transpose2d output")
+        _same_storage(x, y, "conv_transpose2d (channels-last)")
         k = (KH, KW)
         # conv geometry: X = y (image side, Cx = Co), Y = x (feature side, Cy = Ci)
         d = _desc(N, Co, OH, OW, Ci, h, wd, k, stride, pad, yct, xct, act, slope)

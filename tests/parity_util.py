@@ -120,3 +120,28 @@ def flush_report(path="gpurun_out/parity_report.txt"):
         f.write("gradient rows so far: " + ", ".join("%s %d" % kv for kv in TALLY.items()) +
                 " (uninformative rows are not passes: torch fp32 itself is > 1 %% from fp64 there)\n")
     del REPORT[:]
+
+
+# the rounding model of the bf16-storage island (oracle.restate.ISLAND_ROUNDING = (RoundBf16.apply, RoundBf16Forward.apply))
+class RoundBf16(torch.autograd.Function):
+    """what a bf16-stored tensor is: rounded (RNE) on the way forward AND its gradient rounded on the way back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class RoundBf16Forward(torch.autograd.Function):
+    """a bf16 COPY of an fp32 master weight: rounded forward, its gradient stays fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g

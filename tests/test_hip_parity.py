@@ -19,7 +19,7 @@ from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
 
-from parity_util import REPORT, TOL, check, check_grad, flush_report, pop_margins, rel
+from parity_util import REPORT, TOL, RoundBf16, RoundBf16Forward, check, check_grad, flush_report, pop_margins, rel
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -907,30 +907,6 @@ def test_train_step_bf16_close_to_fp32():
     assert rel < 0.4 and cos > 0.93, (rel, cos)
 
 
-class _RoundBf16(torch.autograd.Function):
-    """what a bf16-stored tensor is: rounded (RNE) on the way forward AND its gradient rounded on the way back"""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
-
-    @staticmethod
-    def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
-
-
-class _RoundBf16Forward(torch.autograd.Function):
-    """a bf16 COPY of an fp32 master weight: rounded forward, its gradient stays fp32"""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
-
-    @staticmethod
-    def backward(ctx, g):
-        return g
-
-
 def test_bf16_storage_step_against_bf16_rounding_oracle():
     """BASELINE.json configs 3-4 (bf16): one pre-training step at 32 bars with the channels-last island in bf16 STORAGE
     against the oracle run in fp64 with the SAME rounding model -- every island convolution sees bf16-rounded activations
@@ -982,7 +958,7 @@ def test_bf16_storage_step_against_bf16_rounding_oracle():
             R.ISLAND_ROUNDING = None
         return float(lo.detach()), dict(zip(names, og))
 
-    lo_r, g_r = oracle((_RoundBf16.apply, _RoundBf16Forward.apply))
+    lo_r, g_r = oracle((RoundBf16.apply, RoundBf16Forward.apply))
     lo_x, g_x = oracle(None)
     REPORT.append("bf16 step (32 bars): loss hip %.6f  rounding oracle %.6f  exact %.6f" % (hip_loss, lo_r, lo_x))
     assert abs(hip_loss - lo_r) <= max(2 * abs(lo_r - lo_x), 2e-3 * abs(lo_x)), (hip_loss, lo_r, lo_x)

@@ -243,6 +243,77 @@ def test_channels_last_blocks_against_oracle(mode):
             assert p.grad.data_ptr() >= opt.grad.data_ptr()          # accumulated straight into the flat gradient
 
 
+BF16_BLOCKS = ["residual64", "pooling64", "residual128", "residual512", "pooling512", "deconv_pp1024", "deconv_pp512", "deconv256", "deconv128"]
+
+
+@pytest.mark.parametrize("tag", BF16_BLOCKS)
+def test_channels_last_blocks_bf16_storage_against_rounding_oracle(tag):
+    """every block type of the island in bf16 STORAGE (BASELINE.json configs 3-4) against the fp64 oracle under the
+    island's rounding model (oracle.restate.ISLAND_ROUNDING: conv operands and results bf16, gradients bf16, weight
+    gradients fp32).  The model explains the bf16 mode: the HIP block sits within 4e-3 of it forward (one final bf16
+    store) and within a quarter of the distance between the rounding oracle and exact arithmetic (4 - 7 %) backward."""
+    import graph.encodingBlock as EB
+    import graph.decoder as DD
+    from hipops import FlatParams
+    from hipops import functional as HF
+    from oracle import restate as R, weights as W
+    from parity_util import RoundBf16, RoundBf16Forward
+    mk, prefix, ofn, shape = {
+        "residual64": (lambda: EB.ResidualModule(64, True), "encoder.layers.0.", R.residual_module, (3, 64, 48, 30)),
+        "pooling64": (lambda: EB.PoolingModule(64, 128, True), "encoder.layers.1.", R.pooling_module, (3, 64, 48, 30)),
+        "residual128": (lambda: EB.ResidualModule(128, True), "encoder.layers.2.", R.residual_module, (2, 128, 24, 15)),
+        "residual512": (lambda: EB.ResidualModule(512, True), "encoder.layers.6.", R.residual_module, (3, 512, 6, 4)),
+        "pooling512": (lambda: EB.PoolingModule(512, 1024, True), "encoder.layers.7.", R.pooling_module, (3, 512, 6, 4)),
+        "deconv_pp1024": (lambda: DD.DeConvPitchPadding(1024, 512, True), "decoder.layers.0.", R.deconv_pitch_padding, (3, 1024, 6, 3)),
+        "deconv_pp512": (lambda: DD.DeConvPitchPadding(512, 256, True), "decoder.layers.1.", R.deconv_pitch_padding, (3, 512, 12, 7)),
+        "deconv256": (lambda: DD.DeConvModule(256, 128, True), "decoder.layers.2.", R.deconv_module, (2, 256, 24, 15)),
+        "deconv128": (lambda: DD.DeConvModule(128, 64, True), "decoder.layers.3.", R.deconv_module, (2, 128, 48, 30))}[tag]
+    gsd = W.make_state_dict(W.manifest_generator(), 0, "wc")
+    l2 = lambda a, b: float((a.detach().double().cpu() - b.detach().double()).norm() / b.detach().double().norm().clamp_min(1e-300))
+    mod = mk()
+    sub = {k[len(prefix):]: v for k, v in gsd.items() if k.startswith(prefix)}
+    mod.load_state_dict(sub)
+    mod = mod.to(dev)
+    opt = FlatParams(list(mod.parameters()))
+    opt.zero_grad()
+    x = torch.randn(shape).relu_().bfloat16().float()                # what the block receives is a stored bf16 tensor
+    res = {}
+    dy = None
+    for name, rounding in (("round", (RoundBf16.apply, RoundBf16Forward.apply)), ("exact", None)):
+        osd = {k: v.clone().double().requires_grad_(True) for k, v in sub.items()}
+        xr = x.double().requires_grad_(True)
+        R.ISLAND_ROUNDING = rounding
+        try:
+            yr = ofn(osd, "", xr)
+            if dy is None:
+                dy = torch.randn_like(yr).bfloat16().double()
+            yr.backward(dy)
+        finally:
+            R.ISLAND_ROUNDING = None
+        res[name] = (yr.detach(), xr.grad, {k: v.grad for k, v in osd.items()})
+    HF.set_compute_dtype("bf16")
+    try:
+        xd = x.to(dev).requires_grad_(True)
+        y = mod(HF.to_channels_last(xd))
+        assert y.dtype == torch.bfloat16
+        y.backward(dy.float().to(dev).to(y.dtype))
+        torch.cuda.synchronize()
+    finally:
+        HF.set_compute_dtype("f32")
+    f_hr, f_rx = l2(y.float(), res["round"][0]), l2(res["round"][0], res["exact"][0])
+    d_hr, d_rx = l2(xd.grad, res["round"][1]), l2(res["round"][1], res["exact"][1])
+    REPORT.append("bf16 block %-14s fwd |hip-round| %.2e |round-exact| %.2e   dx |hip-round| %.2e |round-exact| %.2e" % (tag, f_hr, f_rx, d_hr, d_rx))
+    assert f_hr <= 4e-3, (f_hr, f_rx)
+    assert d_hr <= max(1.2e-2, 0.25 * d_rx), (d_hr, d_rx)
+    for n, p in mod.named_parameters():
+        gr, gx = res["round"][2][n], res["exact"][2][n]
+        if gr is None or gr.numel() < 256:
+            continue
+        e, m = l2(p.grad, gr), l2(gr, gx)
+        REPORT.append("    d%-40s |hip-round| %.2e |round-exact| %.2e" % (n, e, m))
+        assert e <= max(1.5e-2, 0.3 * m), (n, e, m)
+
+
 @pytest.mark.parametrize("shape", [(3, 64, 96, 60), (2, 128, 48, 30), (2, 256, 24, 15), (3, 512, 12, 7)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_instance_norm_channels_last(shape, act):
