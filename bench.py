@@ -262,8 +262,8 @@ def main():
         eager_step(*batch)           # per-launch events need real launches (not a graph replay)
         torch.cuda.synchronize()
         HF.FORK_WGRAD, HF.FORK_BRANCHES, gm.OVERLAP_TRUNKS = saved
-        recs = (nat.ProfRec * 64)()
-        n = L.mgvae_prof_collect(recs, 64)
+        recs = (nat.ProfRec * 128)()
+        n = L.mgvae_prof_collect(recs, 128)
         L.mgvae_prof_enable(0)
         L.mgvae_prof_detail(b"")
         conv = [r for r in recs[:n] if r.kind < 5 or r.kind >= 8]          # NCHW + channels-last conv families

@@ -1411,7 +1411,7 @@ static void choice_load_locked() {
         for (int i = 0; i < 14; ++i) n += fscanf(fp, "%d", &k.v[i]);
         n += fscanf(fp, "%d %d", &c.tile, &c.split);
         if (n != 16) break;
-        if (c.tile >= 0 && c.tile < 4 && c.split >= 1 && c.split <= 4096) g_choice[k] = c;
+        if (c.tile >= 0 && c.tile < 12 && c.split >= 1 && c.split <= 4096) g_choice[k] = c;     // tile / 4: loop form of the x3 family
     }
     fclose(fp);
 }
@@ -1873,14 +1873,15 @@ extern "C" int mgvae_prof_detail(const char* path) {
 
 extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    MgvaeProfRec recs[MGVAE_PROF_KINDS * 7];
+    constexpr int SLOTS = 12;          // variant ids per kind (the x3 family has 3 loop forms x 4 tile shapes)
+    MgvaeProfRec recs[MGVAE_PROF_KINDS * SLOTS];
     for (int k = 0; k < MGVAE_PROF_KINDS; ++k)
-        for (int t = 0; t < 7; ++t) recs[k * 7 + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
+        for (int t = 0; t < SLOTS; ++t) recs[k * SLOTS + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
     for (auto& pe : g_prof_entries) {
         float ms = 0.f;
         hipEventSynchronize(pe.e1);
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
-        MgvaeProfRec& r = recs[pe.kind * 7 + pe.tile];
+        MgvaeProfRec& r = recs[pe.kind * SLOTS + (pe.tile < SLOTS ? pe.tile : 0)];
         r.launches += 1; r.ms += ms; r.flops += pe.flops;
         if (g_prof_detail && (pe.kind < 5 || pe.kind >= MGVAE_PROF_NHWC_FWD)) {
             const IgemmP& q = pe.p;
@@ -1893,7 +1894,7 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     g_prof_entries.clear();
     if (g_prof_detail) fflush(g_prof_detail);
     int n = 0;
-    for (int i = 0; i < MGVAE_PROF_KINDS * 7 && n < cap; ++i)
+    for (int i = 0; i < MGVAE_PROF_KINDS * SLOTS && n < cap; ++i)
         if (recs[i].launches > 0) out[n++] = recs[i];
     return n;
 }
@@ -1901,11 +1902,12 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
     static char buf[5][7][48];
-    static char nbuf[9][7][48];
-    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 9 && tile >= 0 && tile < 4) {
+    static char nbuf[9][12][48];
+    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 9 && tile >= 0 && tile < (kind >= MGVAE_PROF_NHWC_X3_FWD ? 12 : 4)) {
         const int m = kind - MGVAE_PROF_NHWC_FWD;
-        static const char* fam[3] = {"nhwc_igemm_kernel<%d, %s>", "nhwc_igemm_bf16_kernel<%d, %s>", "nhwc_igemm_x3_kernel<%d, %s>"};
-        snprintf(nbuf[m][tile], 48, fam[m / 3], m % 3, tiles[tile]);
+        static const char* fam[5] = {"nhwc_igemm_kernel<%d, %s>", "nhwc_igemm_bf16_kernel<%d, %s>", "nhwc_igemm_x3_kernel<%d, %s>",
+                                     "nhwc_igemm_x3s_kernel<%d, %s>", "nhwc_igemm_x3w_kernel<%d, %s>"};
+        snprintf(nbuf[m][tile], 48, fam[m / 3 + tile / 4], m % 3, tiles[tile & 3]);
         return nbuf[m][tile];
     }
     if (kind == MGVAE_PROF_ADAM) return "adam_kernel";
