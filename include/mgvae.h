@@ -139,6 +139,11 @@ int mgvae_conv2d_nhwc_bf16_bwd_weight(const MgvaeConvDesc* d, const void* x, con
  * into wk3 [3, Cy, KH*KW, Cx] (forward) and wt3 [3, Cx, KH*KW, Cy] (data gradient / transposed-conv forward), bf16.
  * Channel counts multiples of 16, slice offsets multiples of 4.                                                         */
 int mgvae_pack_conv_weights_x3(const float* w, void* wk3, void* wt3, int Cy, int T, int Cx, void* stream);
+/* every conv weight of a network in one launch per optimizer step: `items` is a DEVICE array of n records
+ * {const float* w; void* wk; void* wt; int32 Cy, T, Cx, block0} (40 bytes; block0 = running sum of
+ * T * ceil(Cy / 32) * ceil(Cx / 32)), total_blocks that sum over all records; planes = 3: the x3 split (layouts of
+ * mgvae_pack_conv_weights_x3), planes = 1: the bf16 copies of mgvae_pack_conv_weights_bf16.                           */
+int mgvae_pack_conv_weights_grouped(const void* items, int n, int total_blocks, int planes, void* stream);
 int mgvae_conv2d_nhwc_x3_fwd(const MgvaeConvDesc* d, const float* x, const void* wk3, const float* bias, float* y,
                              const MgvaeActMask* mask, void* stream);
 int mgvae_conv2d_nhwc_x3_bwd_data(const MgvaeConvDesc* d, const float* y, const void* wt3, const float* bias, float* x,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mgvae_conv2d_nhwc_bf16_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_bf16_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_pack_conv_weights_x3": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "mgvae_pack_conv_weights_grouped": (c_int, [P, c_int, c_int, c_int, P]),
     "mgvae_conv2d_nhwc_x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_x3_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_x3_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),

@@ -1168,29 +1168,112 @@ def _cl_mask(t, act, slope):
     return nat.ActMask(t.data_ptr(), ct, 0, act, slope), t
 
 
+class _WeightCopies:
+    """the matrix-pipe copies of a network's conv weights -- planes = 1: bf16 (wk [Cy, T, Cx], wt [Cx, T, Cy]) for the
+    bf16-storage island; planes = 3: the three-way split (wk3 [3, Cy, T, Cx], wt3 [3, Cx, T, Cy]) of the fp32 island
+    (csrc/conv_nhwc_x3.inc) -- refreshed ONCE per optimizer step.  A weight inside a FlatParams buffer registers here the
+    first time a conv uses it (and is packed alone that once); from the next step on all registered weights are repacked
+    by one grouped launch when the first of them is asked for, and every other stream that asks waits for that launch's
+    event.  (A parameter outside a flat buffer is repacked whenever torch's version counter moves.)"""
+
+    def __init__(self, planes):
+        self.planes = planes
+        self.copies = {}          # id(w) -> (w, wk, wt)
+        self.table = None         # device table of the grouped launch, rebuilt when the set of weights changed
+        self.blocks = 0
+        self.version = None       # owner.weights_version the copies belong to
+        self.event = None
+        self.waited = set()
+
+    def _alloc(self, w):
+        n = self.planes * w.numel()
+        return (torch.empty(n, device=w.device, dtype=torch.bfloat16), torch.empty(n, device=w.device, dtype=torch.bfloat16))
+
+    def _pack_one(self, w, wk, wt):
+        cy, cx, kh, kw = w.shape
+        fn = nat.lib().mgvae_pack_conv_weights_x3 if self.planes == 3 else nat.lib().mgvae_pack_conv_weights_bf16
+        nat.check(fn(_p(w), _p(wk), _p(wt), cy, kh * kw, cx, _s()), "pack_conv_weights")
+
+    def _build_table(self, device):
+        rec = np.zeros(len(self.copies), dtype=np.dtype([("w", "<u8"), ("wk", "<u8"), ("wt", "<u8"), ("Cy", "<i4"), ("T", "<i4"),
+                                                       ("Cx", "<i4"), ("block0", "<i4")]))
+        blocks = 0
+        for i, (w, wk, wt) in enumerate(self.copies.values()):
+            cy, cx, kh, kw = w.shape
+            rec[i] = (w.data_ptr(), wk.data_ptr(), wt.data_ptr(), cy, kh * kw, cx, blocks)
+            blocks += kh * kw * ((cy + 31) // 32) * ((cx + 31) // 32)
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        self.blocks = blocks
+
+    def get(self, w, version):
+        key = id(w)
+        cur = (version, w._version)           # the owner counts optimizer steps; torch counts in-place edits (load_state_dict ...)
+        if key not in self.copies:
+            wk, wt = self._alloc(w)
+            self.copies[key] = (w, wk, wt)
+            self.table = None
+            self._pack_one(w, wk, wt)
+            w._mg_copy_version = cur
+            return wk, wt
+        _, wk, wt = self.copies[key]
+        if getattr(w, "_mg_copy_version", None) == cur:
+            self._wait()
+            return wk, wt
+        if self.version != version:
+            if self.table is None:
+                self._build_table(w.device)
+            nat.check(nat.lib().mgvae_pack_conv_weights_grouped(_p(self.table), len(self.copies), self.blocks, self.planes, _s()),
+                      "pack_conv_weights_grouped")
+            self.version = version
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream())
+            self.waited = {torch.cuda.current_stream().cuda_stream}
+            for ww, _, _ in self.copies.values():
+                ww._mg_copy_version = (version, ww._version)
+        else:                                  # edited by a torch op inside the step: this one alone
+            self._pack_one(w, wk, wt)
+            w._mg_copy_version = cur
+        self._wait()
+        return wk, wt
+
+    def _wait(self):
+        if self.event is None:
+            return
+        sid = torch.cuda.current_stream().cuda_stream
+        if sid not in self.waited:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.waited.add(sid)
+
+
+def _weight_copies(w, planes, attr):
+    owner = getattr(w, "_mg_owner", None)
+    if owner is None:
+        # a free-standing parameter: repacked whenever torch's version counter moves
+        ver = (w._version, w.data_ptr())
+        c = getattr(w, attr, None)
+        if c is None or c[0] != ver or torch.cuda.is_current_stream_capturing():
+            g = _WeightCopies(planes)
+            wk, wt = (c[1], c[2]) if c is not None else g._alloc(w)
+            g._pack_one(w, wk, wt)
+            c = (ver, wk, wt)
+            setattr(w, attr, c)
+        return c[1], c[2]
+    groups = owner.__dict__.setdefault("_mg_weight_copies", {})
+    g = groups.get(planes)
+    if g is None:
+        g = groups[planes] = _WeightCopies(planes)
+    return g.get(w, owner.weights_version[0])
+
+
 def _bf16_weights(w):
     """(wk, wt): bf16 copies of the fp32 channels-last master weight ``w`` -- wk [Cy, T, Cx] for the forward product, wt
-    [Cx, T, Cy] for the data gradient -- repacked once per optimizer step (FlatParams counts the steps; a parameter outside
-    a flat buffer is repacked whenever torch's version counter moves)."""
-    owner = getattr(w, "_mg_owner", None)
-    ver = (owner.weights_version[0] if owner is not None else -1, w._version, w.data_ptr())
-    c = getattr(w, "_mg_bf16", None)
-    if c is None or c[0] != ver or torch.cuda.is_current_stream_capturing():
-        cy, cx, kh, kw = w.shape
-        if c is None:
-            wk = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
-            wt = torch.empty(w.numel(), device=w.device, dtype=torch.bfloat16)
-        else:
-            wk, wt = c[1], c[2]
-        nat.check(nat.lib().mgvae_pack_conv_weights_bf16(_p(w), _p(wk), _p(wt), cy, kh * kw, cx, _s()), "pack_conv_weights_bf16")
-        c = (ver, wk, wt)
-        w._mg_bf16 = c
-    return c[1], c[2]
+    [Cx, T, Cy] for the data gradient (see _WeightCopies)."""
+    return _weight_copies(w, 1, "_mg_bf16")
 
 
 # fp32 islands: which matrix instruction multiplies.  "x3" (default): csrc/conv_nhwc_x3.inc -- every fp32 operand enters the
 # bf16 matrix pipe as the exact sum of three bf16 values, every product as six bf16 MFMAs (fp32-grade: relative error
-# < 2^-22 per product, fp32 accumulation; tests/test_nhwc_gpu.py holds it to twice the fp32 instruction's own error);
+# < 2^-22 per product, fp32 accumulation; tests/test_nhwc_gpu.py holds it to three times the fp32 instruction's own error);
 # "mfma32": csrc/conv_nhwc.inc on v_mfma_f32_32x32x2_f32.  Same tensors, same results to fp32 rounding.
 FP32_ENGINE = _os.environ.get("MGVAE_FP32_ENGINE", "x3")
 if FP32_ENGINE not in ("x3", "mfma32"):
@@ -1203,21 +1286,8 @@ def _x3_ok(cx, cy):
 
 def _x3_weights(w):
     """(wk3, wt3): the fp32 channels-last master weight as three bf16 planes each way -- wk3 [3, Cy, T, Cx] for the forward
-    product, wt3 [3, Cx, T, Cy] for the data gradient -- re-split once per optimizer step (see _bf16_weights)."""
-    owner = getattr(w, "_mg_owner", None)
-    ver = (owner.weights_version[0] if owner is not None else -1, w._version, w.data_ptr())
-    c = getattr(w, "_mg_x3", None)
-    if c is None or c[0] != ver or torch.cuda.is_current_stream_capturing():
-        cy, cx, kh, kw = w.shape
-        if c is None:
-            wk = torch.empty(3 * w.numel(), device=w.device, dtype=torch.bfloat16)
-            wt = torch.empty(3 * w.numel(), device=w.device, dtype=torch.bfloat16)
-        else:
-            wk, wt = c[1], c[2]
-        nat.check(nat.lib().mgvae_pack_conv_weights_x3(_p(w), _p(wk), _p(wt), cy, kh * kw, cx, _s()), "pack_conv_weights_x3")
-        c = (ver, wk, wt)
-        w._mg_x3 = c
-    return c[1], c[2]
+    product, wt3 [3, Cx, T, Cy] for the data gradient (see _WeightCopies)."""
+    return _weight_copies(w, 3, "_mg_x3")
 
 
 class _ToChannelsLastFn(torch.autograd.Function):

@@ -196,6 +196,7 @@ class GraphedPretrainStep:
         from . import _native as nat
         st, opt = self.step_obj, self.step_obj.opt
         note, pre_note, phrase, position = self.inputs
+        opt.weights_version[0] += 1          # the matrix-pipe copies of the conv weights are re-made once per step (captured too)
         opt.zero_grad()
         loss, gen, _ = st.forward_loss(note, pre_note, phrase, position, self.is_pretraining)
         loss.backward()

@@ -118,9 +118,25 @@ def test_sampling_forward_and_loop_at_32_songs(monkeypatch):
     assert tuple(roll.shape) == (songs, length * 384, 60)
     diff = int((roll != want_roll).sum())
     REPORT.append("sampling loop 32 songs x %d phrases: %d of %d cells differ from the oracle loop" % (length, diff, roll.numel()))
-    # an autoregressive loop amplifies a single threshold flip (a sigmoid output within fp32 noise of 0.3); none is
-    # expected on the well-conditioned weights, a handful would still be fp32 noise
-    assert diff <= 1e-4 * roll.numel(), diff
+    # An autoregressive loop amplifies a single threshold flip: a sigmoid output within fp32 noise of 0.3 binarises the
+    # other way, the next bar is conditioned on a different previous bar, and that song's rolls part ways for good.
+    # Songs are independent batch entries, so every song that differs must be EXPLAINED by such a flip: in the first bar
+    # where it differs, every differing cell's oracle output lies within 1e-4 of the threshold (the single calls above
+    # pin the forward at 1e-3 of the largest output; measured 1e-6 .. 1e-5); at most 3 of the 32 songs may do so.
+    bars_h = roll.reshape(songs, length * 4, 96, 60)
+    bars_o = want_roll.reshape(songs, length * 4, 96, 60)
+    parted = 0
+    for sng in range(songs):
+        bad = [b for b in range(length * 4) if not torch.equal(bars_h[sng, b], bars_o[sng, b])]
+        if not bad:
+            continue
+        parted += 1
+        b0 = bad[0]
+        cells = bars_h[sng, b0] != bars_o[sng, b0]
+        margin = (raw[b0][sng, 0][cells] - 0.3).abs().max().item()
+        REPORT.append("    song %d parts ways in bar %d: %d cells, farthest oracle output %.2e from the 0.3 threshold" % (sng, b0, int(cells.sum()), margin))
+        assert margin < 1e-4, (sng, b0, margin)
+    assert parted <= 3, parted
 
 
 # ------------------------------------------------------------------------------------------ agent iterations
@@ -186,8 +202,27 @@ def _compare_net(tag, module, hip_grads, oracle_grads, ref32_grads, osd, sd0, lr
         assert bad <= 2e-2, (tag, n, bad)
 
 
-def _oracle(kind, sds, lr, batch, noise, masks, dtype):
+def _with_perturbed(o32, run, seeds=(101, 102, 103)):
+    """the gradient dictionaries of the plain fp32 oracle run and of a few 2-ulp-perturbed ones, row by row as lists
+    (parity_util.check_grad takes the worst of them as the row's fp32 noise floor)"""
+    extra = [run(s) for s in seeds]
+    out = dict(o32)
+    for k, v in o32.items():
+        if k.startswith("grad_") and isinstance(v, dict):
+            out[k] = {n: ([t] + [e[k][n] for e in extra] if t is not None else None) for n, t in v.items()}
+    return out
+
+
+def _oracle(kind, sds, lr, batch, noise, masks, dtype, perturb=None):
     osd = {n: S.leaf_copy(sd, dtype) for n, sd in sds.items()}
+    if perturb is not None:
+        # every weight moved by at most two ulps: a stand-in for "the same arithmetic, summed in another order"
+        g = torch.Generator().manual_seed(perturb)
+        with torch.no_grad():
+            for sd in osd.values():
+                for t in sd.values():
+                    if t.is_floating_point():
+                        t.mul_(1.0 + 2.0 ** -22 * (2.0 * torch.rand(t.shape, generator=g, dtype=torch.float32).to(t.dtype) - 1.0))
     b = tuple(t.to(dtype) if t.is_floating_point() else t for t in batch)
     mk = [m.to(dtype) for m in masks]
     if kind == "wae":
@@ -219,6 +254,7 @@ def test_train_wae_iteration_against_oracle(tmp_path, monkeypatch):
     torch.cuda.synchronize()
     o, osd = _oracle("wae", sds, lr, batch, noise, masks, torch.float64)
     o32, _ = _oracle("wae", sds, lr, batch, noise, masks, torch.float32)
+    o32 = _with_perturbed(o32, lambda seed: _oracle("wae", sds, lr, batch, noise, masks, torch.float32, perturb=seed)[0])
     check("train_wae phraseZ discriminator loss", meters["z_phrase"].val, o["phrase_loss"])
     check("train_wae barZ discriminator loss", meters["z_bar"].val, o["bar_loss"])
     check("train_wae generator loss", meters["generator"].val, o["generator_loss"])
@@ -249,6 +285,7 @@ def test_train_gan_iteration_against_oracle(tmp_path, monkeypatch):
     torch.cuda.synchronize()
     o, osd = _oracle("gan", sds, lr, batch, noise, masks, torch.float64)
     o32, _ = _oracle("gan", sds, lr, batch, noise, masks, torch.float32)
+    o32 = _with_perturbed(o32, lambda seed: _oracle("gan", sds, lr, batch, noise, masks, torch.float32, perturb=seed)[0])
     check("train_gan bar discriminator loss", meters["discriminator"].val, o["note_loss"])
     check("train_gan feature discriminator loss", meters["discriminator_feature"].val, o["feature_loss"])
     check("train_gan generator loss", meters["generator"].val, o["generator_loss"])
