@@ -297,7 +297,8 @@ def main():
                 "measured_in": "one extra untimed step with the side streams off (kernels alone on the chip); "
                                "profiles/ holds rocprofv3 of the same command under MGVAE_SERIAL=1",
                 "all_conv_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
-                                     "frac": tot_fl / (tot_ms * 1e-3) / 1e12 / peak,
+                                     # each variant priced against its own family's peak: flops / sum(time_k * peak_k)
+                                     "frac": tot_fl / (sum(f_["ms"] * 1e-3 * f_["peak"] * 1e12 for f_ in fam)),
                                      "share_of_step_time": tot_ms / (1e3 * dt / args.steps)},
                 "variants": fam,
                 "hbm": hbm}
