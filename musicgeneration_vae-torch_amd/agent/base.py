@@ -191,8 +191,10 @@ class AgentBase(object):
         if self.world > 1:
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=False)
-        return DataLoader(dataset, batch_size=self.batch_size, shuffle=False, num_workers=1, sampler=sampler,
-                          pin_memory=self.config.pin_memory, collate_fn=self.make_batch)
+        # the reference forks one loader worker (agent/barGen2.py:41); config.num_workers = 0 loads in-process (a forked
+        # child of a process that has initialised the GPU runtime occasionally dies at exit on this ROCm: the tests use 0)
+        return DataLoader(dataset, batch_size=self.batch_size, shuffle=False, num_workers=int(getattr(self.config, "num_workers", 1)),
+                          sampler=sampler, pin_memory=self.config.pin_memory, collate_fn=self.make_batch)
 
     def to_device(self, *tensors):
         nb = bool(self.config.async_loading)

@@ -34,8 +34,8 @@ def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
     """Gradient parity against an fp64 reference ``want``.  Rules, in this order (the first that holds is recorded):
 
       strict          max|got - want| <= tol * max|want| + atol;
-      (``ref32`` may be a list: the plain fp32 run of the oracle plus runs with every weight moved by <= 2 ulp -- what a
-      different but equally legitimate fp32 summation order does to the row; the worst of them is the row's noise floor.)
+      (``ref32`` may be a list: the plain fp32 run of the oracle plus runs with every weight moved by <= 2e-6 relative -- what
+      a different but equally legitimate fp32 summation order / matrix pipe does to the row; the worst of them is the row's noise floor.)
       uninformative   (needs ref32) torch's own fp32 result of the same quantity is > 1 % from fp64 (sums of huge
                       cancelling terms over planes of exactly tied values): nothing can be concluded from the row; it is
                       NOT counted as a pass, only required to be no worse than 10 x torch fp32 (a wrong kernel is);
@@ -74,7 +74,7 @@ def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
         rule = "strict"
     elif ref32 is not None:
         # ``ref32`` may be several fp32 runs of the reference's own arithmetic (the plain one and runs whose weights were
-        # perturbed by one or two ulps): the row's noise floor is the worst of them
+        # perturbed by <= 2e-6 relative): the row's noise floor is the worst of them
         refs = ref32 if isinstance(ref32, (list, tuple)) else [ref32]
         e32 = l2_32 = 0.0
         for r in refs:

@@ -154,6 +154,7 @@ def _agent(tmp_path, monkeypatch):
         pretraining_step_size = 0
         seed = 5
         log_file = os.path.join(root, "train_epoch.log")
+        num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
     agent = BarGen(Cfg())
     sds = {"generator": W.make_state_dict(W.manifest_generator(), 0, "wc"),
@@ -203,7 +204,7 @@ def _compare_net(tag, module, hip_grads, oracle_grads, ref32_grads, osd, sd0, lr
 
 
 def _with_perturbed(o32, run, seeds=(101, 102, 103)):
-    """the gradient dictionaries of the plain fp32 oracle run and of a few 2-ulp-perturbed ones, row by row as lists
+    """the gradient dictionaries of the plain fp32 oracle run and of a few perturbed ones (weights moved by <= 2e-6 relative), row by row as lists
     (parity_util.check_grad takes the worst of them as the row's fp32 noise floor)"""
     extra = [run(s) for s in seeds]
     out = dict(o32)
@@ -216,13 +217,14 @@ def _with_perturbed(o32, run, seeds=(101, 102, 103)):
 def _oracle(kind, sds, lr, batch, noise, masks, dtype, perturb=None):
     osd = {n: S.leaf_copy(sd, dtype) for n, sd in sds.items()}
     if perturb is not None:
-        # every weight moved by at most two ulps: a stand-in for "the same arithmetic, summed in another order"
+        # every weight moved by <= 2e-6 relative (2^-19): the size of an fp32 dot product's own accumulation error over the
+        # model's K = 576 .. 4608 -- a stand-in for "the same arithmetic, summed in another order / on another pipe"
         g = torch.Generator().manual_seed(perturb)
         with torch.no_grad():
             for sd in osd.values():
                 for t in sd.values():
                     if t.is_floating_point():
-                        t.mul_(1.0 + 2.0 ** -22 * (2.0 * torch.rand(t.shape, generator=g, dtype=torch.float32).to(t.dtype) - 1.0))
+                        t.mul_(1.0 + 2.0 ** -19 * (2.0 * torch.rand(t.shape, generator=g, dtype=torch.float32).to(t.dtype) - 1.0))
     b = tuple(t.to(dtype) if t.is_floating_point() else t for t in batch)
     mk = [m.to(dtype) for m in masks]
     if kind == "wae":

@@ -461,8 +461,9 @@ def test_generator_forward_against_golden(golden_dir, mode):
 
 
 def _fp32_floor(gsd, zsd, inputs, names, seeds=(101, 102, 103)):
-    """gradients of the fp32 oracle step and of runs whose generator weights were moved by <= 2 ulp ("the same arithmetic
-    summed in another order"): per name a list of tensors, the noise floor parity_util.check_grad judges a row against"""
+    """gradients of the fp32 oracle step and of runs whose generator weights were moved by <= 2e-6 relative (2^-19: the size
+    of an fp32 dot product's own accumulation error at the model's K -- "the same arithmetic summed in another order / on
+    another pipe"): per name a list of tensors, the noise floor parity_util.check_grad judges a row against"""
     note, pre, phrase, pos = inputs
     runs = []
     for seed in (None,) + tuple(seeds):
@@ -471,7 +472,7 @@ def _fp32_floor(gsd, zsd, inputs, names, seeds=(101, 102, 103)):
             g = torch.Generator().manual_seed(seed)
             for t in osd32.values():
                 if t.is_floating_point():
-                    t.mul_(1.0 + 2.0 ** -22 * (2.0 * torch.rand(t.shape, generator=g) - 1.0))
+                    t.mul_(1.0 + 2.0 ** -19 * (2.0 * torch.rand(t.shape, generator=g) - 1.0))
         osd32 = {k: (v.requires_grad_(True) if v.is_floating_point() else v) for k, v in osd32.items()}
         lo32, _ = R.pretrain_step_loss(osd32, zsd, zsd, note, pre, phrase, pos, True)
         runs.append(torch.autograd.grad(lo32, [osd32[n] for n in names], allow_unused=True))
@@ -511,7 +512,7 @@ def test_train_step_against_oracle_and_golden(golden_dir):
     lo, _ = R.pretrain_step_loss(osd, z64, z64, note.double(), pre.double(), phrase.double(), pos, True)
     names = list(gn["grad"].keys())
     og = torch.autograd.grad(lo, [osd[n] for n in names])
-    og32 = _fp32_floor(gsd, zsd, (note, pre, phrase, pos), names)       # plain fp32 + three 2-ulp-perturbed runs
+    og32 = _fp32_floor(gsd, zsd, (note, pre, phrase, pos), names)       # plain fp32 + three perturbed runs
     params = dict(m.named_parameters())
     gscale = max(g.abs().max().item() for g in og)
     worst, worst_ref = 0.0, 0.0
@@ -584,7 +585,7 @@ def test_full_size_step_parity_and_batch_properties():
     lo, _ = R.pretrain_step_loss(osd, z64, z64, note.double(), pre.double(), phrase.double(), pos, True)
     og = torch.autograd.grad(lo, [osd[n] for n in names], allow_unused=True)
     del osd
-    og32 = _fp32_floor(gsd, zsd, (note, pre, phrase, pos), names, seeds=(101,))      # plain fp32 + one 2-ulp-perturbed run
+    og32 = _fp32_floor(gsd, zsd, (note, pre, phrase, pos), names, seeds=(101,))      # plain fp32 + one perturbed run
     check("full-size step loss vs oracle fp64", loss64, lo.detach(), 1e-4)
     gscale = max(g.abs().max().item() for g in og if g is not None)
     pop_margins("(rows before the full-size step)", 0)
