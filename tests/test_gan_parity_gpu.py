@@ -140,7 +140,7 @@ def test_sampling_forward_and_loop_at_32_songs(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------ agent iterations
-def _agent(tmp_path, monkeypatch):
+def _agent(tmp_path, monkeypatch, compute_dtype="f32"):
     from test_agent_gpu import _make_dataset
     from config import Config
     from agent.barGen_with_gan import BarGen
@@ -156,6 +156,7 @@ def _agent(tmp_path, monkeypatch):
         log_file = os.path.join(root, "train_epoch.log")
         num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
+    Cfg.compute_dtype = compute_dtype
     agent = BarGen(Cfg())
     sds = {"generator": W.make_state_dict(W.manifest_generator(), 0, "wc"),
            "discriminator": W.make_state_dict(W.manifest_bar_discriminator(), 0, "wc"),
@@ -307,3 +308,55 @@ def test_train_gan_iteration_against_oracle(tmp_path, monkeypatch):
         elif k.endswith("num_batches_tracked") and int(v) > 0:
             assert int(hsd[k]) == int(v) == 3, (k, int(hsd[k]), int(v))
     assert set(grads) == {"generator", "discriminator", "discriminator_feature"}
+
+
+def test_train_gan_iteration_bf16_storage(tmp_path, monkeypatch):
+    """BASELINE.json configs[3] (barGen_with_gan, bf16): the same GAN iteration with ``config.compute_dtype = 'bf16'`` --
+    the generator's island in bf16 storage, the discriminators (outside the island) fp32 -- against the fp64 oracle WITH
+    the island's rounding model.  The discriminator steps see only the generator's forward: their losses must match to
+    1 % and their gradients in direction; the generator's own gradient is judged like the 32-bar step
+    (test_bf16_storage_step_against_bf16_rounding_oracle): as close to the rounding oracle as that is to exact arithmetic."""
+    from hipops import functional as HF
+    from parity_util import RoundBf16, RoundBf16Forward
+    agent, sds, grads = _agent(tmp_path, monkeypatch, "bf16")
+    try:
+        assert HF.get_compute_dtype() == "bf16"
+        lr = agent.config.learning_rate
+        batch = W.make_inputs(4, seed=32)
+        noise = torch.randn(4, 1152, generator=torch.Generator().manual_seed(9)) * 1.5
+        masks = _masks(4, 4)
+        monkeypatch.setattr(agent, "prior", lambda rows, sigma: noise.to(dev))
+        agent.generator.decoder._drop_masks = [m.to(dev) for m in masks]
+        agent.epoch = 1
+        from metrics import AverageMeter
+        meters = {k: AverageMeter() for k in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+        agent.train_gan(*(t.to(dev) for t in batch), meters, 0)
+        torch.cuda.synchronize()
+    finally:
+        HF.set_compute_dtype("f32")
+    o_x, _ = _oracle("gan", sds, lr, batch, noise, masks, torch.float64)
+    R.ISLAND_ROUNDING = (RoundBf16.apply, RoundBf16Forward.apply)
+    try:
+        o_r, _ = _oracle("gan", sds, lr, batch, noise, masks, torch.float64)
+    finally:
+        R.ISLAND_ROUNDING = None
+    for key, meter in (("note_loss", "discriminator"), ("feature_loss", "discriminator_feature"), ("generator_loss", "generator")):
+        got, want, exact = float(meters[meter].val), float(o_r[key]), float(o_x[key])
+        REPORT.append("bf16 train_gan %-16s hip %.6f  rounding oracle %.6f  exact %.6f" % (key, got, want, exact))
+        assert abs(got - want) <= max(2 * abs(want - exact), 1e-2 * abs(exact)), (key, got, want, exact)
+
+    def flat(d, names):
+        return torch.cat([d[n].detach().double().cpu().reshape(-1) for n in names])
+    for net, okey in (("discriminator", "grad_discriminator"), ("discriminator_feature", "grad_discriminator_feature"),
+                      ("generator", "grad_generator")):
+        names = [n for n, g in o_x[okey].items() if g is not None and n in grads[net]]
+        fh, fr, fx = flat(grads[net], names), flat(o_r[okey], names), flat(o_x[okey], names)
+        e_hip = float((fh - fr).norm() / fr.norm()); e_model = float((fr - fx).norm() / fx.norm())
+        cos = float((fh * fr).sum() / (fh.norm() * fr.norm()))
+        REPORT.append("bf16 train_gan d%-22s |hip - rounding oracle| %.3e   |rounding oracle - exact| %.3e   cos %.4f" % (net, e_hip, e_model, cos))
+        # (the fake bar is binarised at 0.3 before the discriminators see it: bf16 rounding flips cells, so even the
+        # discriminators' gradients move by 20 - 40 % between the rounding oracle and exact arithmetic)
+        assert e_hip <= 1.5 * max(e_model, 2e-2), (net, e_hip, e_model)
+        assert cos >= 1.0 - 1.5 * max(e_model, 2e-2) ** 2, (net, cos, e_model)
+    assert agent.opt_discriminator.step_count == 1 and agent.opt_generator.step_count == 1
+
