@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--variational", action="store_true")
     ap.add_argument("--transport", default=None)
     ap.add_argument("--agent", action="store_true")
+    ap.add_argument("--dtype", default="f32", help="bf16: BASELINE.json configs[2] (bf16 storage inside the island, data parallel)")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend = os.environ.get("MGVAE_DIST_BACKEND", "gloo")
@@ -108,6 +109,7 @@ def main():
         return run_agent(rank, world, dev)
     from hipops import functional as HF
     from oracle.weights import make_inputs
+    HF.set_compute_dtype(args.dtype)
     batch = make_inputs(2 * world, seed=99)
     shard = tuple(t[rank::world].contiguous().to(dev) for t in batch)
     step = build(dev, 1, args.variational, args.transport)
@@ -146,7 +148,15 @@ def main():
         print("DPCHECK same_across_ranks=%s grad_l2_rel=%.3e outlier_frac=%.3e max_dw=%.3e moved=%.3e side_streams=%d early_buckets=%s"
               % (same, l2, frac, dw, moved, n_streams, early))
         tol = 2e-2 if args.transport != "bf16" else 3e-2       # bf16 wire: 2^-9 per addend and per sum
-        ok = same and l2 < tol and frac < 2e-2 + (0.3 if args.transport == "bf16" else 0.0) and moved > 0
+        loose = 0.3 if args.transport == "bf16" else 0.0
+        if args.dtype == "bf16":
+            # bf16 storage: the two-rank run sees 2-bar shards (other tiles / tuner choices than the 4-bar reference step),
+            # and a 4-bar bf16 step is chaotic at bf16 resolution: direction and size must agree
+            cos = float((g_dp * g_ref).sum() / (g_dp.norm() * g_ref.norm()))
+            print("DPCHECK bf16 cosine=%.4f" % cos)
+            tol, loose = 0.6, 1.0
+            ok = cos > 0.8
+        ok = ok and same and l2 < tol and frac < 2e-2 + loose and moved > 0
         ok = ok and n_streams <= 2                             # phrase trunk + ONE weight-gradient stream
         # early buckets: the decoder's always; the bar-encoder trunk's only when both passes ran stacked
         ok = ok and len(early) == (1 if args.variational else 2)

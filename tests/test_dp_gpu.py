@@ -42,6 +42,14 @@ def test_two_rank_step_bf16_gradient_transport():
     _run(29614, "--transport", "bf16")
 
 
+def test_two_rank_step_bf16_storage():
+    """BASELINE.json configs[2]'s shape of run (bf16 storage inside the island + data parallel) at two ranks: identical
+    weights on both ranks, stream budget, early buckets, and the all-reduced gradient agrees with the single-process bf16
+    step in direction and size"""
+    out = _run(29616, "--dtype", "bf16")
+    assert "DPCHECK bf16 cosine" in out
+
+
 def test_first_agent_two_ranks_unseeded_across_the_pretraining_boundary(tmp_path):
     _run(29615, "--agent", env_extra={"MGVAE_TEST_ROOT": str(tmp_path)}, timeout=900)
 
