@@ -455,6 +455,9 @@ def test_generator_forward_against_golden(golden_dir, mode):
     ref_err = rel(t("gen"), t("gen64"))
     tol = max(TOL, 2 * ref_err)
     check("e2e[%s] gen vs fp64 oracle (torch fp32 itself: %.2e)" % (mode, ref_err), gen, t("gen64"), tol)
+    # ... and against the reference's OWN fp32 output (north_star: "1e-3 rel vs reference CPU forward"): two fp32
+    # evaluations of an ill-conditioned decoder can each be ref_err from the truth, so that is the bar on the d4 weights
+    check("e2e[%s] gen vs the reference's fp32 fixture" % mode, gen, t("gen"), max(TOL, 2 * ref_err))
     flips = int(((gen.cpu().numpy() > 0.3) != (fx["gen64"] > 0.3)).sum())
     REPORT.append("e2e[%s] binarised mismatches vs fp64: %d of %d" % (mode, flips, gen.numel()))
     assert flips <= (3 if mode == "d4" else 0)
