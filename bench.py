@@ -154,7 +154,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP hot path has no CPU fallback")
-    local_rank = local_rank % max(1, torch.cuda.device_count())   # tests may stack ranks on one GPU (gloo)
+    if os.environ.get("MGVAE_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # gloo test ranks may share the one GPU of a test box
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("LOCAL_RANK=%d but %d GPU(s) visible: one process per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist

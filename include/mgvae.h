@@ -127,10 +127,15 @@ int mgvae_conv2d_nhwc_bwd_weight(const MgvaeConvDesc* d, const float* x, const f
  * gradient -- bias fp32, accumulation fp32 (v_mfma_f32_32x32x16_bf16), the weight gradient is ADDED to the fp32 master
  * gradient dw [Cy, KH*KW, Cx].  Channel counts multiples of 64, slice offsets multiples of 8 (csrc/conv_nhwc_bf16.inc).   */
 int mgvae_pack_conv_weights_bf16(const float* w, void* wk, void* wt, int Cy, int T, int Cx, void* stream);
+/* `ws, ws_bytes`: CALLER-OWNED split-K workspace (the library allocates nothing).  mgvae_conv2d_nhwc_bf16_workspace(d, mode)
+ * -- mode 0 forward, 1 data gradient / transposed-conv forward, 2 weight gradient (always 0) -- returns the bytes the largest
+ * deterministic split the tuner may pick for this geometry needs; 0 when the launch fills the chip unsplit.  A null or short
+ * workspace is legal: the split shrinks to what fits (same values up to summation order of the K chunks).                 */
+size_t mgvae_conv2d_nhwc_bf16_workspace(const MgvaeConvDesc* d, int mode);
 int mgvae_conv2d_nhwc_bf16_fwd(const MgvaeConvDesc* d, const void* x, const void* wk, const float* bias, void* y,
-                               const MgvaeActMask* mask, void* stream);
+                               const MgvaeActMask* mask, void* ws, size_t ws_bytes, void* stream);
 int mgvae_conv2d_nhwc_bf16_bwd_data(const MgvaeConvDesc* d, const void* y, const void* wt, const float* bias, void* x,
-                                    const MgvaeActMask* mask, void* stream);
+                                    const MgvaeActMask* mask, void* ws, size_t ws_bytes, void* stream);
 int mgvae_conv2d_nhwc_bf16_bwd_weight(const MgvaeConvDesc* d, const void* x, const void* y, float* dw, void* stream);
 /* fp32-STORAGE forms on the bf16 matrix pipe ("x3", csrc/conv_nhwc_x3.inc): same tensors and results as the fp32 entry
  * points above (x / y / dw fp32, fp32 accumulation), but every fp32 operand value enters the matrix pipe as the exact sum
@@ -144,10 +149,12 @@ int mgvae_pack_conv_weights_x3(const float* w, void* wk3, void* wt3, int Cy, int
  * T * ceil(Cy / 32) * ceil(Cx / 32)), total_blocks that sum over all records; planes = 3: the x3 split (layouts of
  * mgvae_pack_conv_weights_x3), planes = 1: the bf16 copies of mgvae_pack_conv_weights_bf16.                           */
 int mgvae_pack_conv_weights_grouped(const void* items, int n, int total_blocks, int planes, void* stream);
+/* workspace: as for the bf16 family above (caller-owned, size from mgvae_conv2d_nhwc_x3_workspace, null / short is legal) */
+size_t mgvae_conv2d_nhwc_x3_workspace(const MgvaeConvDesc* d, int mode);
 int mgvae_conv2d_nhwc_x3_fwd(const MgvaeConvDesc* d, const float* x, const void* wk3, const float* bias, float* y,
-                             const MgvaeActMask* mask, void* stream);
+                             const MgvaeActMask* mask, void* ws, size_t ws_bytes, void* stream);
 int mgvae_conv2d_nhwc_x3_bwd_data(const MgvaeConvDesc* d, const float* y, const void* wt3, const float* bias, float* x,
-                                  const MgvaeActMask* mask, void* stream);
+                                  const MgvaeActMask* mask, void* ws, size_t ws_bytes, void* stream);
 int mgvae_conv2d_nhwc_x3_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw, void* stream);
 
 int mgvae_conv2d_bwd_weight(const MgvaeConvDesc* d, const float* x, const float* y, float* dw,

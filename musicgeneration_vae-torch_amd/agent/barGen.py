@@ -93,6 +93,53 @@ class BarGen(AgentBase):
         self.net_gen.reducer.wait()
         opt.step(grad_scale=1.0 / hdist.world_size())
 
+    def train_iteration(self, note, pre_note, pre_phrase, position, curr_it, div_flag, meters):
+        """one pass of the loop body of agent/barGen.py:231-335; ``meters`` = (gen, disc, z_bar, z_phrase) AverageMeters"""
+        avg_gen, avg_disc, avg_zbar, avg_zphrase = meters
+        adversarial = self.epoch > self.pretraining_step_size
+        for n in (self.net_gen, self.net_disc, self.net_zbar, self.net_zphrase):
+            n.zero_grad()
+        if (curr_it + self.epoch) % div_flag == 1 and adversarial:
+            for m in (self.discriminator, self.z_discriminator_bar, self.z_discriminator_phrase):
+                self.free(m)
+            self.frozen(self.generator)
+            gen_note, z, pre_z, phrase_feature = self.generator(note, pre_note, pre_phrase, position)
+            b = z.size(0)
+            # this agent labels real -> valid and prior -> fake (opposite of barGen2), sigma = 1 (:265,:271)
+            phrase_fake = self.prior(b, 1.0)
+            phrase_loss = C(self.z_discriminator_phrase(phrase_feature).view(-1), 1.0) + \
+                C(self.z_discriminator_phrase(phrase_fake).view(-1), 0.0)
+            bar_fake = self.prior(2 * b, 1.0)
+            bar_loss = C(self.z_discriminator_bar(z).view(-1), 1.0) + C(self.z_discriminator_bar(pre_z).view(-1), 1.0) + \
+                C(self.z_discriminator_bar(bar_fake).view(-1), 0.0)
+            fake = HF.cat_time(pre_note, torch.gt(gen_note, 0.3).float())
+            d_fake = self.discriminator(fake).view(-1)              # fake pair first (BatchNorm statistics: :281,:284)
+            disc_loss = C(d_fake, 0.0) + C(self.discriminator(HF.cat_time(pre_note, note)).view(-1), 1.0)
+            disc_loss.backward(); phrase_loss.backward(); bar_loss.backward()
+            self.net_disc.step(); self.net_zbar.step(); self.net_zphrase.step()
+            avg_disc.update(disc_loss); avg_zbar.update(bar_loss); avg_zphrase.update(phrase_loss)
+        self.free(self.generator)
+        for m in (self.discriminator, self.z_discriminator_bar, self.z_discriminator_phrase):
+            self.frozen(m)
+        gen_note, z, pre_z, phrase_feature = self.generator(note, pre_note, pre_phrase, position)
+        if adversarial:
+            # D7: the smoothed reconstruction loss is computed by the reference and then overwritten
+            gen_loss = C(self.z_discriminator_phrase(phrase_feature).view(-1), 1.0)
+            gen_loss = gen_loss + C(self.z_discriminator_bar(z).view(-1), 1.0) + C(self.z_discriminator_bar(pre_z).view(-1), 1.0)
+            fake = HF.cat_time(pre_note, torch.gt(gen_note, 0.3).float())
+            gen_loss = gen_loss + C(self.discriminator(fake).view(-1), 1.0)
+            gen_loss.backward()
+            self._gen_step(self.opt_gen2)
+        else:
+            gen_loss = self.loss_gen(gen_note, note, True)
+            gen_loss.backward()
+            self._gen_step(self.opt_gen1)
+        avg_gen.update(gen_loss)
+        return gen_note
+
+    def prior(self, rows, sigma):
+        return HF.randn((rows, 1152), sigma, self.device)
+
     def train_epoch(self):
         it_total = (len(self.dataset) + self.batch_size * self.world - 1) // (self.batch_size * self.world)
         batches = tqdm(self.dataloader, total=it_total, desc="epoch-{}".format(self.epoch), disable=self.rank != 0)
@@ -105,42 +152,9 @@ class BarGen(AgentBase):
         for curr_it, batch in enumerate(batches):
             note, pre_note, pre_phrase, position = self.to_device(*batch)
             self.iteration += 1
-            for n in (self.net_gen, self.net_disc, self.net_zbar, self.net_zphrase):
-                n.zero_grad()
-            if (curr_it + self.epoch) % div_flag == 1 and adversarial:
-                for m in (self.discriminator, self.z_discriminator_bar, self.z_discriminator_phrase):
-                    self.free(m)
-                self.frozen(self.generator)
-                gen_note, z, pre_z, phrase_feature = self.generator(note, pre_note, pre_phrase, position)
-                b = z.size(0)
-                # this agent labels real -> valid and prior -> fake (opposite of barGen2)
-                phrase_loss = C(self.z_discriminator_phrase(phrase_feature).view(-1), 1.0) + \
-                    C(self.z_discriminator_phrase(HF.randn((b, 1152), 1.0, self.device)).view(-1), 0.0)
-                bar_loss = C(self.z_discriminator_bar(z).view(-1), 1.0) + C(self.z_discriminator_bar(pre_z).view(-1), 1.0) + \
-                    C(self.z_discriminator_bar(HF.randn((2 * b, 1152), 1.0, self.device)).view(-1), 0.0)
-                fake = HF.cat_time(pre_note, torch.gt(gen_note, 0.3).float())
-                disc_loss = C(self.discriminator(fake).view(-1), 0.0) + C(self.discriminator(HF.cat_time(pre_note, note)).view(-1), 1.0)
-                disc_loss.backward(); phrase_loss.backward(); bar_loss.backward()
-                self.net_disc.step(); self.net_zbar.step(); self.net_zphrase.step()
-                avg_disc.update(disc_loss); avg_zbar.update(bar_loss); avg_zphrase.update(phrase_loss)
-            self.free(self.generator)
-            for m in (self.discriminator, self.z_discriminator_bar, self.z_discriminator_phrase):
-                self.frozen(m)
-            gen_note, z, pre_z, phrase_feature = self.generator(note, pre_note, pre_phrase, position)
-            image_sample, origin_image = gen_note, note
-            if adversarial:
-                # D7: the smoothed reconstruction loss is computed by the reference and then overwritten
-                gen_loss = C(self.z_discriminator_phrase(phrase_feature).view(-1), 1.0)
-                gen_loss = gen_loss + C(self.z_discriminator_bar(z).view(-1), 1.0) + C(self.z_discriminator_bar(pre_z).view(-1), 1.0)
-                fake = HF.cat_time(pre_note, torch.gt(gen_note, 0.3).float())
-                gen_loss = gen_loss + C(self.discriminator(fake).view(-1), 1.0)
-                gen_loss.backward()
-                self._gen_step(self.opt_gen2)
-            else:
-                gen_loss = self.loss_gen(gen_note, note, True)
-                gen_loss.backward()
-                self._gen_step(self.opt_gen1)
-            avg_gen.update(gen_loss)
+            image_sample = self.train_iteration(note, pre_note, pre_phrase, position, curr_it, div_flag,
+                                                (avg_gen, avg_disc, avg_zbar, avg_zphrase))
+            origin_image = note
         batches.close()
         if image_sample is None:
             return

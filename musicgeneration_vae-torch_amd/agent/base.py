@@ -78,6 +78,17 @@ class ReduceLROnPlateau:
         self.best, self.num_bad, self.cooldown_counter = sd["best"], sd["num_bad"], sd["cooldown_counter"]
 
 
+def collate_batch(samples):
+    """the reference's ``make_batch`` (agent/barGen2.py:128-135): a batch is the concatenation of its items along axis 0.
+    Module-level so that spawned loader workers can unpickle it (AgentBase.make_loader)."""
+    cat = lambda k: np.concatenate([s[k] for s in samples], axis=0)
+    if "note_bits" in samples[0]:           # packed: ship the bits, expand them in to_device
+        return (torch.from_numpy(cat("note_bits")), torch.from_numpy(cat("pre_note_bits")),
+                torch.from_numpy(cat("pre_phrase_bits")), torch.from_numpy(cat("position").astype(np.int64)))
+    return (torch.tensor(cat("note"), dtype=torch.float), torch.tensor(cat("pre_note"), dtype=torch.float),
+            torch.tensor(cat("pre_phrase"), dtype=torch.float), torch.tensor(cat("position"), dtype=torch.long))
+
+
 class Net:
     """a network + its flat Adam + its gradient reducer + its LR scheduler"""
 
@@ -122,7 +133,14 @@ class AgentBase(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
             raise RuntimeError("the BarGen agents of this build need a ROCm GPU (no CPU fallback for the HIP hot path)")
-        self.local_rank %= max(1, torch.cuda.device_count())     # tests stack several gloo ranks on the one GPU of a box
+        ndev = torch.cuda.device_count()
+        if self.local_rank >= ndev:
+            # one process per GPU.  Only the tests (gloo ranks stacked on the single GPU of a test box) may share a
+            # device, and they say so; under RCCL two ranks on one device is a duplicate-GPU error or a hang
+            if os.environ.get("MGVAE_STACK_RANKS", "0") == "0":
+                raise RuntimeError("LOCAL_RANK=%d but only %d GPU(s) are visible: one process per GPU "
+                                   "(MGVAE_STACK_RANKS=1 lets gloo test ranks share a device)" % (self.local_rank, ndev))
+            self.local_rank %= max(1, ndev)
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank)
         if self.world > 1 and not torch.distributed.is_initialized():
@@ -162,12 +180,7 @@ class AgentBase(object):
         return NoteDataset(self.config.root_path, self.config)
 
     def make_batch(self, samples):
-        cat = lambda k: np.concatenate([s[k] for s in samples], axis=0)
-        if "note_bits" in samples[0]:           # packed: ship the bits, expand them in to_device
-            return (torch.from_numpy(cat("note_bits")), torch.from_numpy(cat("pre_note_bits")),
-                    torch.from_numpy(cat("pre_phrase_bits")), torch.from_numpy(cat("position").astype(np.int64)))
-        return (torch.tensor(cat("note"), dtype=torch.float), torch.tensor(cat("pre_note"), dtype=torch.float),
-                torch.tensor(cat("pre_phrase"), dtype=torch.float), torch.tensor(cat("position"), dtype=torch.long))
+        return collate_batch(samples)
 
     def free(self, module):
         for p in module.parameters():
@@ -191,10 +204,29 @@ class AgentBase(object):
         if self.world > 1:
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=False)
-        # the reference forks one loader worker (agent/barGen2.py:41); config.num_workers = 0 loads in-process (a forked
-        # child of a process that has initialised the GPU runtime occasionally dies at exit on this ROCm: the tests use 0)
-        return DataLoader(dataset, batch_size=self.batch_size, shuffle=False, num_workers=int(getattr(self.config, "num_workers", 1)),
-                          sampler=sampler, pin_memory=self.config.pin_memory, collate_fn=self.make_batch)
+        # The reference runs ONE loader worker (agent/barGen2.py:41), and so does this build by default.  What differs is
+        # how the worker comes to life.  torch's default on Linux is fork(): the child of a process that has initialised
+        # the GPU runtime inherits libhsa-runtime64 / libamdhip64 state (queue and doorbell mappings, signal pools, the
+        # runtimes' atexit and static destructors) WITHOUT the runtimes' helper threads, and it runs those destructors
+        # when it exits at the end of an epoch -- that is the `DataLoader worker (pid N) is killed by signal:
+        # Segmentation fault` round 2 recorded (the parent had initialised HIP, dlopen'ed libmgvae_hip.so and held pinned
+        # host rings when it forked).  So no worker is ever forked from this process: workers are SPAWNED (a fresh
+        # interpreter that never touches the GPU; the dataset and the module-level ``collate_batch`` travel by pickle)
+        # and kept alive across epochs (``persistent_workers``: one start-up per run instead of one fork per epoch).
+        # config.num_workers = 0 loads in-process.
+        workers = int(getattr(self.config, "num_workers", 1))
+        extra = {}
+        if workers > 0:
+            extra = dict(multiprocessing_context="spawn", persistent_workers=True)
+        return DataLoader(dataset, batch_size=self.batch_size, shuffle=False, num_workers=workers, sampler=sampler,
+                          pin_memory=self.config.pin_memory, collate_fn=collate_batch, **extra)
+
+    def close_loader(self):
+        """stop the persistent loader workers now (they would otherwise be stopped when the loader is collected)"""
+        it = getattr(getattr(self, "dataloader", None), "_iterator", None)
+        if it is not None and hasattr(it, "_shutdown_workers"):
+            it._shutdown_workers()
+            self.dataloader._iterator = None
 
     def to_device(self, *tensors):
         nb = bool(self.config.async_loading)

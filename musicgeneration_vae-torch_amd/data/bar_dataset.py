@@ -2,12 +2,33 @@
 ``root_dir/config.data_path`` with keys note, pre_note [k,1,96,60], pre_phrase [k,1,384,60] and
 position [k]; a batch is the concatenation of its items along axis 0 (agent ``make_batch``)."""
 import os
+import types
 
 import numpy as np
 from torch.utils.data import Dataset
 
 
-class NoteDataset(Dataset):
+def _plain_config(config):
+    """the scalar settings of a Config object as a plain namespace.  Loader workers of this build are spawned, not forked
+    (agent/base.py::make_loader), so the dataset travels to them by pickle -- and a Config subclass defined inside a
+    function, as experiments and tests do, does not pickle."""
+    out = types.SimpleNamespace()
+    for k in dir(config):
+        if not k.startswith("_"):
+            v = getattr(config, k)
+            if isinstance(v, (int, float, str, bool, type(None))):
+                setattr(out, k, v)
+    return out
+
+
+class _Picklable(Dataset):
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["config"] = _plain_config(state["config"])
+        return state
+
+
+class NoteDataset(_Picklable):
     def __init__(self, root_dir, config):
         self.root_dir = root_dir
         self.config = config
@@ -56,7 +77,7 @@ def pack_dataset(src_dir, dst_file):
     return int(sum(len(p) for p in pos))
 
 
-class PackedNoteDataset(Dataset):
+class PackedNoteDataset(_Picklable):
     """same role as NoteDataset over ONE packed file (``config.packed_data_file`` under ``root_dir``, made by
     ``pack_dataset``); an item is ONE sample (dict of uint8 rows + position), so ``batch_size`` counts samples here,
     whereas NoteDataset's items are files that may hold several samples each"""

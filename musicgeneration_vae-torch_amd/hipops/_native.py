@@ -50,13 +50,15 @@ SIGNATURES = {
     "mgvae_conv2d_nhwc_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
     "mgvae_conv2d_nhwc_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_pack_conv_weights_bf16": (c_int, [P, P, P, c_int, c_int, c_int, P]),
-    "mgvae_conv2d_nhwc_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
-    "mgvae_conv2d_nhwc_bf16_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_bf16_workspace": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "mgvae_conv2d_nhwc_bf16_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P, c_size_t, P]),
+    "mgvae_conv2d_nhwc_bf16_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P, c_size_t, P]),
     "mgvae_conv2d_nhwc_bf16_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_pack_conv_weights_x3": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "mgvae_pack_conv_weights_grouped": (c_int, [P, c_int, c_int, c_int, P]),
-    "mgvae_conv2d_nhwc_x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
-    "mgvae_conv2d_nhwc_x3_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P]),
+    "mgvae_conv2d_nhwc_x3_workspace": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "mgvae_conv2d_nhwc_x3_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P, c_size_t, P]),
+    "mgvae_conv2d_nhwc_x3_bwd_data": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, ctypes.POINTER(ActMask), P, c_size_t, P]),
     "mgvae_conv2d_nhwc_x3_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P]),
     "mgvae_conv_pack_floats": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "mgvae_conv_pack": (c_int, [ctypes.POINTER(ConvDesc), c_int, P, P, P]),

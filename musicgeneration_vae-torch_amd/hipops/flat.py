@@ -95,6 +95,14 @@ class FlatParams:
         h[0], h[1], h[2], h[3] = lr / bc1, math.sqrt(bc2), b1, b2
         self._hyper.copy_(h, non_blocking=True)
 
+    def invalidate_weight_copies(self):
+        """the flat weights were changed behind the kernels' back (a restore, a graph replay whose captured repack ran
+        BEFORE its Adam node): the matrix-pipe copies of the conv weights (hipops.functional._WeightCopies) are stale for
+        the next eager launch.  Also forgets an event recorded inside a stream capture."""
+        self.weights_version[0] += 1
+        for g in self.__dict__.get("_mg_weight_copies", {}).values():
+            g.event, g.waited = None, set()
+
     def step_range(self, start, end, grad_scale=1.0):
         """Adam over the flat slice [start, end) on the current stream (after begin_step on a stream it is ordered behind)"""
         if end <= start:

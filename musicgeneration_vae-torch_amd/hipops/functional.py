@@ -1290,6 +1290,24 @@ def _x3_weights(w):
     return _weight_copies(w, 3, "_mg_x3")
 
 
+_ws_bytes = {}      # (family, mode, geometry) -> bytes of the largest deterministic split-K the tuner may pick (0: never split)
+
+
+def _split_ws(fam, d, mode, device):
+    """the CALLER-OWNED split-K workspace of one channels-last forward / data-gradient launch (include/mgvae.h:
+    mgvae_conv2d_nhwc_{x3,bf16}_workspace): a tensor from torch's caching allocator on the launching stream (the library
+    allocates nothing), or None when the geometry never splits.  Returns (tensor-or-None, pointer, bytes)."""
+    key = (fam, mode, d.N, d.Cx, d.H, d.W, d.Cy, d.KH, d.KW, d.SH, d.SW, d.PH, d.PW)
+    n = _ws_bytes.get(key)
+    if n is None:
+        fn = nat.lib().mgvae_conv2d_nhwc_x3_workspace if fam == "x3" else nat.lib().mgvae_conv2d_nhwc_bf16_workspace
+        n = _ws_bytes[key] = int(fn(ctypes.byref(d), mode))
+    if not n:
+        return None, None, 0
+    t = torch.empty(n, device=device, dtype=torch.uint8)
+    return t, _vp(t.data_ptr()), n
+
+
 class _ToChannelsLastFn(torch.autograd.Function):
     """NCHW fp32 (dense or a channel slice) -> dense channels-last copy of the island's storage type; backward converts the
     gradient back to NCHW fp32"""
@@ -1367,10 +1385,12 @@ class _ConvClFn(torch.autograd.Function):
         d = _desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, yct, act, slope)
         if x.dtype == torch.bfloat16:
             wk, _ = _bf16_weights(w)
-            nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), _p(x), _p(wk), _p(b), _p(y), None, _s()), "conv2d_nhwc_bf16_fwd")
+            wst, wsp, wsn = _split_ws("bf16", d, 0, x.device)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), _p(x), _p(wk), _p(b), _p(y), None, wsp, wsn, _s()), "conv2d_nhwc_bf16_fwd")
         elif _x3_ok(Cx, Cy):
             wk3, _ = _x3_weights(w)
-            nat.check(nat.lib().mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), _p(x), _p(wk3), _p(b), _p(y), None, _s()), "conv2d_nhwc_x3_fwd")
+            wst, wsp, wsn = _split_ws("x3", d, 0, x.device)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), _p(x), _p(wk3), _p(b), _p(y), None, wsp, wsn, _s()), "conv2d_nhwc_x3_fwd")
         else:
             nat.check(nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "conv2d_nhwc_fwd")
         ctx.geom = (N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, act, slope)
@@ -1419,10 +1439,12 @@ class _ConvClFn(torch.autograd.Function):
             mref = ctypes.byref(m) if m is not None else None
             if bf:
                 _, wt = _bf16_weights(w)
-                nat.check(L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d2), _p(dy), _p(wt), None, _p(dx), mref, _s()), "conv2d_nhwc_bf16_bwd_data")
+                wst, wsp, wsn = _split_ws("bf16", d2, 1, dy.device)
+                nat.check(L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d2), _p(dy), _p(wt), None, _p(dx), mref, wsp, wsn, _s()), "conv2d_nhwc_bf16_bwd_data")
             elif _x3_ok(Cx, Cy):
                 _, wt3 = _x3_weights(w)
-                nat.check(L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d2), _p(dy), _p(wt3), None, _p(dx), mref, _s()), "conv2d_nhwc_x3_bwd_data")
+                wst, wsp, wsn = _split_ws("x3", d2, 1, dy.device)
+                nat.check(L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d2), _p(dy), _p(wt3), None, _p(dx), mref, wsp, wsn, _s()), "conv2d_nhwc_x3_bwd_data")
             else:
                 nat.check(L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), mref, _s()), "conv2d_nhwc_bwd_data")
         return dx, None, None, None, None, None, None, None, None, None
@@ -1589,10 +1611,12 @@ class _ConvTClFn(torch.autograd.Function):
         d = _desc(N, Co, OH, OW, Ci, h, wd, k, stride, pad, yct, xct, act, slope)
         if x.dtype == torch.bfloat16:
             _, wt = _bf16_weights(w)
-            nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), _p(x), _p(wt), _p(b), _p(y), None, _s()), "convT_nhwc_bf16_fwd")
+            wst, wsp, wsn = _split_ws("bf16", d, 1, x.device)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), _p(x), _p(wt), _p(b), _p(y), None, wsp, wsn, _s()), "convT_nhwc_bf16_fwd")
         elif _x3_ok(Co, Ci):
             _, wt3 = _x3_weights(w)
-            nat.check(nat.lib().mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), _p(x), _p(wt3), _p(b), _p(y), None, _s()), "convT_nhwc_x3_fwd")
+            wst, wsp, wsn = _split_ws("x3", d, 1, x.device)
+            nat.check(nat.lib().mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), _p(x), _p(wt3), _p(b), _p(y), None, wsp, wsn, _s()), "convT_nhwc_x3_fwd")
         else:
             nat.check(nat.lib().mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), None, _s()), "convT_nhwc_fwd")
         ctx.geom = (N, Co, OH, OW, Ci, h, wd, k, stride, pad, xct, act, slope)
@@ -1634,10 +1658,12 @@ class _ConvTClFn(torch.autograd.Function):
             d2 = _desc(N, Co, OH, OW, Ci, h, wd, k, s, p, dct, Ci, ACT_NONE, 0.0)
             if bf:
                 wk, _ = _bf16_weights(w)
-                nat.check(L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d2), _p(dy), _p(wk), None, _p(dx), None, _s()), "convT_nhwc_bf16_bwd_data")
+                wst, wsp, wsn = _split_ws("bf16", d2, 0, dy.device)
+                nat.check(L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d2), _p(dy), _p(wk), None, _p(dx), None, wsp, wsn, _s()), "convT_nhwc_bf16_bwd_data")
             elif _x3_ok(Co, Ci):
                 wk3, _ = _x3_weights(w)
-                nat.check(L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d2), _p(dy), _p(wk3), None, _p(dx), None, _s()), "convT_nhwc_x3_bwd_data")
+                wst, wsp, wsn = _split_ws("x3", d2, 0, dy.device)
+                nat.check(L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d2), _p(dy), _p(wk3), None, _p(dx), None, wsp, wsn, _s()), "convT_nhwc_x3_bwd_data")
             else:
                 nat.check(L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d2), _p(dy), _p(w), None, _p(dx), None, _s()), "convT_nhwc_bwd_data")
         return dx, None, None, None, None, None, None, None, None

@@ -163,6 +163,7 @@ class GraphedPretrainStep:
         with torch.no_grad():
             opt.flat.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
         opt.step_count = saved[3]
+        opt.invalidate_weight_copies()       # the copies belong to the warm-up's weights, not to the restored ones
         del saved
         self.graph = torch.cuda.CUDAGraph()
         self._refresh_masks()
@@ -170,6 +171,9 @@ class GraphedPretrainStep:
         with torch.cuda.graph(self.graph):
             self.loss, self.gen_out = self._body()
         torch.cuda.synchronize()
+        # capture executed nothing: the copies still hold the warm-up's weights, and the event the repack "recorded" belongs
+        # to the capture (an eager launch must not wait on it)
+        opt.invalidate_weight_copies()
 
     def _refresh_masks(self):
         if self.use_masks:
@@ -225,6 +229,9 @@ class GraphedPretrainStep:
         self.graph.replay()
         self._replayed = torch.cuda.Event()
         self._replayed.record()
+        # the replayed repack ran in FRONT of the replayed Adam: the copies hold the weights of the step before.  The next
+        # replay repacks by itself; an eager forward (validation, sampling) has to as well
+        self.step_obj.opt.invalidate_weight_copies()
         return self.loss, self.gen_out
 
 

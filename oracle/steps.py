@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's GAN-agent iterations and sampling loop.
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's agent iterations (agent/barGen.py adversarial
+branch, agent/barGen_with_gan.py train_wae / train_gan, agent/barGen_with_gan2.py train_discriminator + train_add_gan)
+and of the sampling loop.
 
 The reference's agents cannot be imported on Python >= 3.7 (``async=`` keyword, SURVEY defect D1) and hard-code
 ``.cuda()`` (D3), so these functions restate their per-iteration arithmetic from the source text on top of the
@@ -143,6 +145,117 @@ def gan_iteration(gsd, d_sd, f_sd, opts, batch, noise, drop_masks, run_disc):
     out["generator_loss"], out["gen"], out["gen_z"] = loss.detach(), gen.detach(), gen_z.detach()
     out["grad_generator"] = _grads(loss, gsd)
     opts["generator"].step(out["grad_generator"])
+    return out
+
+
+def bargen_iteration(gsd, d_sd, zb_sd, zp_sd, opts, batch, noise, drop_masks, run_disc):
+    """agent/barGen.py:254-327, one ADVERSARIAL iteration (epoch > pretraining_step_size) of the first agent.
+
+    The generator is graph.model.Model (4-tuple; Refiner left out, defect D2) in train() mode in both of its forwards
+    (:218); BarDiscriminator is in train() mode throughout (:219): its BatchNorm statistics move in the discriminator
+    block (fake pair first, then real: :281-284) AND in the generator block (:320-322), where its parameters are frozen.
+    This agent labels real -> valid and prior -> fake (:268,:275-276), the opposite of barGen2, and draws its priors
+    with sigma = 1 (:265,:271).  The bar discriminator sees the fake bar BINARISED at 0.3 (:279,:320): no gradient
+    reaches the generator through it.  Defect D7 restated: the smoothed reconstruction loss of :314 is overwritten at
+    :316, so the generator's adversarial loss is the three latent terms + the (gradient-free) bar term, and only the
+    encoders receive a gradient; ``opt_gen2`` steps (:327).
+    opts: {"gen2", "discriminator", "z_bar", "z_phrase"}; noise = (phrase_fake [B, 1152], bar_fake [2B, 1152])."""
+    note, pre_note, pre_phrase, position = batch
+    out = {}
+    if run_disc:                                                                                         # :254
+        with torch.no_grad():                                                                            # generator frozen (:260-262)
+            gen, z, pre_z, pf = R.generator_train(gsd, note, pre_note, pre_phrase, position, True, drop_masks)
+        d_phrase_fake = R.z_discriminator(zp_sd, "", noise[0]).view(-1)                                  # :265-267
+        d_phrase_real = R.z_discriminator(zp_sd, "", pf).view(-1)
+        phrase_loss = R.dloss(d_phrase_real, _ones(pf)) + R.dloss(d_phrase_fake, _zeros(pf))             # :268
+        d_bar_fake = R.z_discriminator(zb_sd, "", noise[1]).view(-1)                                     # :271-274
+        d_bar_real1 = R.z_discriminator(zb_sd, "", z).view(-1)
+        d_bar_real2 = R.z_discriminator(zb_sd, "", pre_z).view(-1)
+        bar_loss = R.dloss(d_bar_real1, _ones(z)) + R.dloss(d_bar_real2, _ones(z)) + R.dloss(d_bar_fake, _zeros(noise[1]))   # :275-276
+        fake = torch.cat((pre_note, torch.gt(gen, 0.3).to(gen.dtype)), dim=2)                            # :279-280
+        d_fake = R.bar_discriminator(d_sd, "", fake, train=True).view(-1)                                # :281
+        d_real = R.bar_discriminator(d_sd, "", torch.cat((pre_note, note), dim=2), train=True).view(-1)  # :283-284
+        disc_loss = R.dloss(d_fake, _zeros(z)) + R.dloss(d_real, _ones(z))                               # :286
+        out["disc_loss"], out["phrase_loss"], out["bar_loss"] = disc_loss.detach(), phrase_loss.detach(), bar_loss.detach()
+        out["grad_discriminator"] = _grads(disc_loss, d_sd)                                              # :289-291
+        out["grad_z_phrase"] = _grads(phrase_loss, zp_sd)
+        out["grad_z_bar"] = _grads(bar_loss, zb_sd)
+        opts["discriminator"].step(out["grad_discriminator"])                                            # :293-295
+        opts["z_bar"].step(out["grad_z_bar"])
+        opts["z_phrase"].step(out["grad_z_phrase"])
+    # generator block (:299-327) against the just-updated, frozen discriminators
+    gen, z, pre_z, pf = R.generator_train(gsd, note, pre_note, pre_phrase, position, True, drop_masks)
+    zp = {k: v.detach() for k, v in zp_sd.items()}
+    zb = {k: v.detach() for k, v in zb_sd.items()}
+    dd = {k: (v.detach() if v.is_floating_point() and "running_" not in k else v) for k, v in d_sd.items()}
+    loss = R.dloss(R.z_discriminator(zp, "", pf).view(-1), _ones(pf))                                    # :316 (overwrites :314, D7)
+    loss = loss + R.dloss(R.z_discriminator(zb, "", z).view(-1), _ones(z)) + R.dloss(R.z_discriminator(zb, "", pre_z).view(-1), _ones(z))
+    fake = torch.cat((pre_note, torch.gt(gen, 0.3).to(gen.dtype)), dim=2)                                # :320-321
+    loss = loss + R.dloss(R.bar_discriminator(dd, "", fake, train=True).view(-1), _ones(z))              # :322-324
+    out["generator_loss"], out["gen"] = loss.detach(), gen.detach()
+    out["grad_generator"] = _grads(loss, gsd)
+    opts["gen2"].step(out["grad_generator"])                                                             # :327
+    return out
+
+
+def gan2_iteration(gsd, d_sd, f_sd, zb_sd, zp_sd, opts, batch, noise, drop_masks, sigma=1.0):
+    """agent/barGen_with_gan2.py:345-404 (train_discriminator) followed by :468-519 (train_add_gan): what every iteration
+    after pre-training runs (:287-293).
+
+    Modes: train_add_gan puts the generator and the two latent discriminators in train() mode and BarDiscriminator /
+    BarFeatureDiscriminator in eval() mode (:469-474), and nothing ever switches the latter two back: BarDiscriminator's
+    BatchNorm therefore normalises with its RUNNING statistics in every pass of this agent, and they never move.
+    train_discriminator itself sets no mode: it runs with what the previous iteration's train_add_gan left (the generator
+    in train() mode: dropout on) -- restated here; the first iteration of an epoch, which follows the all-eval sampling
+    block of :308-313, differs only in the generator's dropout being off.
+    This agent labels real -> fake_target (0) and fake / prior -> valid_target (1) in all four discriminators.
+    noise = (phrase_fake [B,1152], bar_fake [B,1152], both already scaled by config.sigma (:358,:365); gan_noise [B,1152]
+    ~ N(0, 1.5^2) of :503).  opts: {"generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase"}."""
+    note, pre_note, pre_phrase, position = batch
+    out = {}
+    # ---- train_discriminator (:345-404)
+    with torch.no_grad():                                                                                # generator frozen (:353-355)
+        gen, z, pre_z, pf, gen_z = R.generator_gan(gsd, note, pre_note, pre_phrase, position, True, True, drop_masks)
+    d_phrase_fake = R.z_discriminator(zp_sd, "", noise[0]).view(-1)                                      # :358-360
+    d_phrase_real = R.z_discriminator(zp_sd, "", pf).view(-1)
+    phrase_loss = R.dloss(d_phrase_real, _zeros(pf)) + R.dloss(d_phrase_fake, _ones(pf))                 # :361-362
+    d_bar_fake = R.z_discriminator(zb_sd, "", noise[1]).view(-1)                                         # :365-367
+    d_bar_real = R.z_discriminator(zb_sd, "", z).view(-1)
+    bar_loss = R.dloss(d_bar_real, _zeros(z)) + R.dloss(d_bar_fake, _ones(z))                            # :368
+    binar = torch.gt(gen, 0.3).to(gen.dtype)                                                             # :371
+    d_note_fake = R.bar_discriminator(d_sd, "", torch.cat((pre_note, binar), dim=2), train=False).view(-1)     # :372-374
+    d_note_real = R.bar_discriminator(d_sd, "", torch.cat((pre_note, note), dim=2), train=False).view(-1)      # :376
+    note_loss = R.dloss(d_note_real, _zeros(z)) + R.dloss(d_note_fake, _ones(z))                         # :376
+    d_feat_fake = R.bar_feature_discriminator(f_sd, "", gen_z).view(-1)                                  # :379-380
+    d_feat_real = R.bar_feature_discriminator(f_sd, "", z).view(-1)
+    feat_loss = R.dloss(d_feat_real, _zeros(z)) + R.dloss(d_feat_fake, _ones(z))                         # :381-382
+    out["phrase_loss"], out["bar_loss"] = phrase_loss.detach(), bar_loss.detach()
+    out["note_loss"], out["feature_loss"] = note_loss.detach(), feat_loss.detach()
+    out["grad_z_phrase"] = _grads(phrase_loss, zp_sd)                                                    # :385-388
+    out["grad_z_bar"] = _grads(bar_loss, zb_sd)
+    out["grad_discriminator"] = _grads(note_loss, d_sd)
+    out["grad_discriminator_feature"] = _grads(feat_loss, f_sd)
+    opts["z_bar"].step(out["grad_z_bar"])                                                                # :390-393
+    opts["z_phrase"].step(out["grad_z_phrase"])
+    opts["discriminator"].step(out["grad_discriminator"])
+    opts["discriminator_feature"].step(out["grad_discriminator_feature"])
+    # ---- train_add_gan (:468-519): every discriminator frozen, at its just-updated weights
+    zp = {k: v.detach() for k, v in zp_sd.items()}
+    zb = {k: v.detach() for k, v in zb_sd.items()}
+    dd = {k: (v.detach() if v.is_floating_point() else v) for k, v in d_sd.items()}
+    ff = {k: v.detach() for k, v in f_sd.items()}
+    gen, z, pre_z, pf, _ = R.generator_gan(gsd, note, pre_note, pre_phrase, position, True, True, drop_masks)   # :488
+    loss = R.dloss(R.z_discriminator(zp, "", pf).view(-1), _ones(pf))                                    # :491-492
+    loss = loss + R.dloss(R.z_discriminator(zb, "", z).view(-1), _ones(z)) + R.dloss(R.z_discriminator(zb, "", pre_z).view(-1), _ones(z))   # :495-497
+    loss = loss + R.bar_loss(gen, note, False)                                                           # :500
+    gen2, gen_z = R.generator_gan(gsd, noise[2], pre_note, pre_phrase, position, False, True, drop_masks)        # :503-504
+    binar = torch.gt(gen2, 0.3).to(gen2.dtype)                                                           # :506
+    d_note_fake = R.bar_discriminator(dd, "", torch.cat((pre_note, binar), dim=2), train=False).view(-1)         # :507
+    loss = loss + R.dloss(d_note_fake, _ones(z)) * 0.05                                                  # :508
+    loss = loss + R.dloss(R.bar_feature_discriminator(ff, "", gen_z).view(-1), _ones(z)) * 0.05          # :510-511
+    out["generator_loss"], out["gen"], out["gen_z"] = loss.detach(), gen2.detach(), gen_z.detach()      # returns gen_note[:3] of :504
+    out["grad_generator"] = _grads(loss, gsd)
+    opts["generator"].step(out["grad_generator"])                                                        # :513-515
     return out
 
 

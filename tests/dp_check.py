@@ -65,7 +65,6 @@ def run_agent(rank, world, dev):
         pretraining_step_size = 1
         seed = None
         log_file = os.path.join(root, "train_epoch.log")
-        num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
     agent = BarGen(Cfg())
     seeds = [None] * world

@@ -37,7 +37,6 @@ def test_bargen2_trains_checkpoints_and_samples(tmp_path):
         pretraining_step_size = 1   # epoch 1 pre-trains, epoch 2 runs the adversarial schedule
         seed = 7
         log_file = os.path.join(root, "train_epoch.log")
-        num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
     agent = BarGen(Cfg())
     before = agent.opt_generator.flat.clone()
@@ -93,7 +92,6 @@ def test_gan_agents_run_every_phase(tmp_path, which):
         pretraining_step_size = 1
         seed = 11
         log_file = os.path.join(root, "train_epoch.log")
-        num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
     mod = importlib.import_module("agent." + which)
     agent = mod.BarGen(Cfg())
@@ -189,7 +187,6 @@ def test_packed_dataset_feeds_the_same_batches(tmp_path):
             seed = 11
             packed_data_file = "data/packed.npz" if packed else None
             log_file = os.path.join(root, "train_epoch.log")
-        num_workers = 0         # in-process loading (agent/base.py::make_loader)
         return Cfg()
 
     a, b = BarGen(cfg(False)), BarGen(cfg(True))

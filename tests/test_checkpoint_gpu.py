@@ -37,7 +37,6 @@ def test_reference_layout_checkpoint_round_trip(tmp_path):
         pretraining_step_size = 5
         seed = 2
         log_file = os.path.join(root, "train_epoch.log")
-        num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
     agent = BarGen(Cfg())                    # loads model/checkpoint.pth.tar in its constructor
     dp, topt = nets["generator"]

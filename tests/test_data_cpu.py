@@ -58,3 +58,43 @@ def test_pack_dataset_rejects_non_binary(tmp_path):
              pre_phrase=np.zeros((1, 1, 384, 60), np.float32), position=np.zeros((1,), np.int64))
     with pytest.raises(ValueError):
         pack_dataset(d, os.path.join(str(tmp_path), "p.npz"))
+
+
+def test_loader_workers_are_spawned_and_persistent(tmp_path):
+    """agent/base.py::make_loader with the DEFAULT config (one worker, like agent/barGen2.py:41): the worker must be a
+    spawned interpreter, never a fork of the training process (a fork of a process that has initialised the GPU runtime
+    is what segfaulted at worker exit in round 2), it must survive from epoch to epoch, and a dataset whose config is a
+    function-local Config subclass must reach it (pickle)."""
+    import multiprocessing as mp
+    import pickle
+    from agent.base import AgentBase, collate_batch
+    from config import Config
+    from data.bar_dataset import NoteDataset
+    root = str(tmp_path)
+    _make(root, n_files=4, per_file=2)
+
+    class Cfg(Config):
+        root_path = root
+        batch_size = 2
+        pin_memory = False
+
+    cfg = Cfg()
+    assert not hasattr(cfg, "num_workers") or cfg.num_workers == 1
+    agent = AgentBase.__new__(AgentBase)           # no GPU here: only the loader plumbing
+    agent.config, agent.batch_size, agent.world, agent.rank = cfg, 2, 1, 0
+    ds = NoteDataset(root, cfg)
+    pickle.loads(pickle.dumps(ds))
+    dl = agent.make_loader(ds)
+    assert dl.num_workers == 1 and dl.persistent_workers
+    assert isinstance(dl.multiprocessing_context, type(mp.get_context("spawn")))
+    assert dl.collate_fn is collate_batch
+    pids = []
+    for epoch in range(2):
+        batches = list(dl)
+        assert len(batches) == 2 and batches[0][0].shape == (4, 1, 96, 60) and batches[0][3].dtype.is_floating_point is False
+        pids.append([w.pid for w in dl._iterator._workers])
+    assert pids[0] == pids[1], "the worker was restarted between epochs"
+    agent.dataloader = dl
+    agent.close_loader()
+    ref = collate_batch([ds[0], ds[1]])
+    assert all((a == b).all() for a, b in zip(ref, batches[0]))

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(port, *args, env_extra=None, timeout=600):
     # MGVAE_FORK_MIN_BATCH=1: the weight gradients are forked onto the side stream even at this tiny batch, so the
     # stream-count check (<= 2 side streams under torch.distributed) sees the streams a full-size step creates
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MGVAE_FORK_MIN_BATCH="1", MGVAE_FORK_WGRAD="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MGVAE_FORK_MIN_BATCH="1", MGVAE_FORK_WGRAD="1",
+               MGVAE_STACK_RANKS="1")     # both gloo ranks share the one GPU of the test box (agent/base.py)
     env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dp_check.py")] + list(args)

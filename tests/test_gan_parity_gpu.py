@@ -140,10 +140,11 @@ def test_sampling_forward_and_loop_at_32_songs(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------ agent iterations
-def _agent(tmp_path, monkeypatch, compute_dtype="f32"):
+def _agent(tmp_path, monkeypatch, compute_dtype="f32", which="barGen_with_gan"):
+    import importlib
     from test_agent_gpu import _make_dataset
     from config import Config
-    from agent.barGen_with_gan import BarGen
+    BarGen = importlib.import_module("agent." + which).BarGen
     root = str(tmp_path)
     _make_dataset(root, n_files=2, per_file=2)
 
@@ -154,7 +155,6 @@ def _agent(tmp_path, monkeypatch, compute_dtype="f32"):
         pretraining_step_size = 0
         seed = 5
         log_file = os.path.join(root, "train_epoch.log")
-        num_workers = 0         # in-process loading (agent/base.py::make_loader)
 
     Cfg.compute_dtype = compute_dtype
     agent = BarGen(Cfg())
@@ -163,11 +163,22 @@ def _agent(tmp_path, monkeypatch, compute_dtype="f32"):
            "discriminator_feature": W.make_state_dict(W.manifest_bar_feature_discriminator(), 0, "wc"),
            "z_discriminator_bar": W.make_state_dict(W.manifest_z_discriminator(), 1, "wc"),
            "z_discriminator_phrase": W.make_state_dict(W.manifest_z_discriminator(), 2, "wc")}
+    nets = getattr(agent, "nets", None)
+    if nets is None:        # agent/barGen.py: no feature discriminator, two Adam states over the generator
+        nets = {"discriminator": agent.net_disc, "z_discriminator_bar": agent.net_zbar, "z_discriminator_phrase": agent.net_zphrase}
+        sds.pop("discriminator_feature")
     for n, sd in sds.items():
         getattr(agent, n).load_state_dict(sd)
     # record the flat gradient of every network at the moment it steps
     grads = {}
-    for n, net in agent.nets.items():
+    if which == "barGen":
+        def gen_step(opt, orig=agent._gen_step):
+            torch.cuda.synchronize()
+            grads["generator"] = {k: p.grad.detach().clone() for k, p in agent.generator.named_parameters()}
+            grads["generator_opt"] = "gen2" if opt is agent.opt_gen2 else "gen1"
+            orig(opt)
+        agent._gen_step = gen_step
+    for n, net in nets.items():
         def wrapped(net=net, n=n, orig=net.step):
             torch.cuda.synchronize()
             grads[n] = {k: p.grad.detach().clone() for k, p in net.module.named_parameters()}
@@ -228,7 +239,18 @@ def _oracle(kind, sds, lr, batch, noise, masks, dtype, perturb=None):
                         t.mul_(1.0 + 2.0 ** -19 * (2.0 * torch.rand(t.shape, generator=g, dtype=torch.float32).to(t.dtype) - 1.0))
     b = tuple(t.to(dtype) if t.is_floating_point() else t for t in batch)
     mk = [m.to(dtype) for m in masks]
-    if kind == "wae":
+    if kind == "bargen":
+        opts = {"gen2": S.AdamState(osd["generator"], lr), "discriminator": S.AdamState(osd["discriminator"], lr),
+                "z_bar": S.AdamState(osd["z_discriminator_bar"], lr), "z_phrase": S.AdamState(osd["z_discriminator_phrase"], lr)}
+        o = S.bargen_iteration(osd["generator"], osd["discriminator"], osd["z_discriminator_bar"], osd["z_discriminator_phrase"],
+                               opts, b, [t.to(dtype) for t in noise], mk, True)
+    elif kind == "gan2":
+        opts = {"generator": S.AdamState(osd["generator"], lr), "discriminator": S.AdamState(osd["discriminator"], lr),
+                "discriminator_feature": S.AdamState(osd["discriminator_feature"], lr),
+                "z_bar": S.AdamState(osd["z_discriminator_bar"], lr), "z_phrase": S.AdamState(osd["z_discriminator_phrase"], lr)}
+        o = S.gan2_iteration(osd["generator"], osd["discriminator"], osd["discriminator_feature"], osd["z_discriminator_bar"],
+                             osd["z_discriminator_phrase"], opts, b, [t.to(dtype) for t in noise], mk)
+    elif kind == "wae":
         opts = {"generator": S.AdamState(osd["generator"], lr), "z_bar": S.AdamState(osd["z_discriminator_bar"], lr),
                 "z_phrase": S.AdamState(osd["z_discriminator_phrase"], lr)}
         o = S.wae_iteration(osd["generator"], osd["z_discriminator_bar"], osd["z_discriminator_phrase"], opts, b,
@@ -308,6 +330,121 @@ def test_train_gan_iteration_against_oracle(tmp_path, monkeypatch):
         elif k.endswith("num_batches_tracked") and int(v) > 0:
             assert int(hsd[k]) == int(v) == 3, (k, int(hsd[k]), int(v))
     assert set(grads) == {"generator", "discriminator", "discriminator_feature"}
+
+
+def _bn_stats(tag, module, osd_d, passes):
+    """BatchNorm running statistics and counters of the bar discriminator after ``passes`` train-mode forwards (0: the
+    module must still hold its initial statistics)"""
+    hsd = module.state_dict()
+    for k, v in osd_d.items():
+        if "running_" in k:
+            check("%s BatchNorm %s" % (tag, k), hsd[k], v)
+        elif k.endswith("num_batches_tracked"):
+            assert int(hsd[k]) == int(v), (k, int(hsd[k]), int(v))
+            assert int(v) in (0, passes), (k, int(v))
+
+
+def test_bargen_adversarial_iteration_against_oracle(tmp_path, monkeypatch):
+    """row a17, agent/barGen.py:254-327 through the agent's own ``train_iteration``: the discriminator block (three
+    networks step: BarDiscriminator on the BINARISED fake pair, both latent discriminators with real -> valid labels and
+    sigma-1 priors) and the generator block with the D7 loss overwrite on ``opt_gen2`` -- every loss, every gradient, the
+    Adam updates, and BatchNorm statistics after three train-mode passes."""
+    agent, sds, grads = _agent(tmp_path, monkeypatch, which="barGen")
+    lr = agent.config.learning_rate
+    batch = W.make_inputs(4, seed=41)
+    g = torch.Generator().manual_seed(18)
+    noise = [torch.randn(4, 1152, generator=g), torch.randn(8, 1152, generator=g)]
+    masks = _masks(4, 6)
+    it = iter(noise)
+
+    def prior(rows, sigma):
+        t = next(it)
+        assert sigma == 1.0 and t.shape[0] == rows       # agent/barGen.py:265,271: unscaled randn, B then 2B rows
+        return t.to(dev)
+    monkeypatch.setattr(agent, "prior", prior)
+    agent.generator.decoder._drop_masks = [m.to(dev) for m in masks]
+    agent.epoch = 1                                      # > pretraining_step_size (0): adversarial
+    for m in (agent.generator, agent.discriminator, agent.z_discriminator_bar, agent.z_discriminator_phrase):
+        m.train()                                        # agent/barGen.py:218-221
+    from metrics import AverageMeter
+    meters = tuple(AverageMeter() for _ in range(4))
+    out = agent.train_iteration(*(t.to(dev) for t in batch), 0, 2, meters)        # (0 + 1) % 2 == 1: both blocks run
+    torch.cuda.synchronize()
+    o, osd = _oracle("bargen", sds, lr, batch, noise, masks, torch.float64)
+    o32, _ = _oracle("bargen", sds, lr, batch, noise, masks, torch.float32)
+    o32 = _with_perturbed(o32, lambda seed: _oracle("bargen", sds, lr, batch, noise, masks, torch.float32, perturb=seed)[0])
+    avg_gen, avg_disc, avg_zbar, avg_zphrase = meters
+    check("barGen bar discriminator loss", avg_disc.val, o["disc_loss"])
+    check("barGen barZ discriminator loss", avg_zbar.val, o["bar_loss"])
+    check("barGen phraseZ discriminator loss", avg_zphrase.val, o["phrase_loss"])
+    check("barGen generator loss (D7: latent + bar terms only)", avg_gen.val, o["generator_loss"])
+    check("barGen returned sample", out, o["gen"], max(TOL, 2e-3))
+    _compare_net("barGen discriminator", agent.discriminator, grads["discriminator"], o["grad_discriminator"],
+                 o32["grad_discriminator"], osd["discriminator"], sds["discriminator"], lr)
+    _compare_net("barGen z_bar", agent.z_discriminator_bar, grads["z_discriminator_bar"], o["grad_z_bar"], o32["grad_z_bar"],
+                 osd["z_discriminator_bar"], sds["z_discriminator_bar"], lr)
+    _compare_net("barGen z_phrase", agent.z_discriminator_phrase, grads["z_discriminator_phrase"], o["grad_z_phrase"],
+                 o32["grad_z_phrase"], osd["z_discriminator_phrase"], sds["z_discriminator_phrase"], lr)
+    _compare_net("barGen generator", agent.generator, grads["generator"], o["grad_generator"], o32["grad_generator"], osd["generator"],
+                 sds["generator"], lr)
+    pop_margins("barGen adversarial iteration vs fp64 oracle", 10)
+    # D7 + the threshold: nothing of the decoder receives a gradient in the adversarial generator block
+    dec = [n for n, gr in o["grad_generator"].items() if n.startswith("decoder.")]
+    assert dec and all(o["grad_generator"][n] is None for n in dec)
+    assert all(float(grads["generator"][n].abs().max()) == 0.0 for n in dec)
+    assert grads["generator_opt"] == "gen2" and agent.opt_gen2.step_count == 1 and agent.opt_gen1.step_count == 0
+    _bn_stats("barGen", agent.discriminator, osd["discriminator"], 3)
+    assert agent.opt_discriminator.step_count == agent.opt_Zdiscriminator_bar.step_count == agent.opt_Zdiscriminator_phrase.step_count == 1
+
+
+def test_bargen_with_gan2_iteration_against_oracle(tmp_path, monkeypatch):
+    """row a17, agent/barGen_with_gan2.py:345-404 + :468-519 through the agent's own ``train_discriminator`` and
+    ``train_add_gan``: all four discriminators step every iteration (BarDiscriminator in eval() mode on the binarised fake
+    pair), then the generator on reconstruction + latent terms + 0.05 x (bar + feature) terms of a bar decoded from
+    N(0, 1.5^2) noise."""
+    agent, sds, grads = _agent(tmp_path, monkeypatch, which="barGen_with_gan2")
+    lr = agent.config.learning_rate
+    batch = W.make_inputs(4, seed=43)
+    g = torch.Generator().manual_seed(28)
+    sigma = agent.config.sigma
+    noise = [torch.randn(4, 1152, generator=g) * sigma, torch.randn(4, 1152, generator=g) * sigma, torch.randn(4, 1152, generator=g) * 1.5]
+    want_sigma = [sigma, sigma, 1.5]
+    masks = _masks(4, 7)
+    k = [0]
+
+    def prior(rows, sg):
+        assert rows == 4 and sg == want_sigma[k[0]], (rows, sg, k[0])
+        k[0] += 1
+        return noise[k[0] - 1].to(dev)
+    monkeypatch.setattr(agent, "prior", prior)
+    agent.generator.decoder._drop_masks = [m.to(dev) for m in masks]
+    agent.epoch = 1
+    # the modes the previous iteration's train_add_gan left (agent/barGen_with_gan2.py:469-474)
+    agent.modes(train=("generator", "z_discriminator_bar", "z_discriminator_phrase"), evaluate=("discriminator", "discriminator_feature"))
+    from metrics import AverageMeter
+    meters = {k_: AverageMeter() for k_ in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+    dbatch = tuple(t.to(dev) for t in batch)
+    agent.train_discriminator(*dbatch, meters)
+    out = agent.train_add_gan(*dbatch, meters)
+    torch.cuda.synchronize()
+    assert k[0] == 3
+    o, osd = _oracle("gan2", sds, lr, batch, noise, masks, torch.float64)
+    o32, _ = _oracle("gan2", sds, lr, batch, noise, masks, torch.float32)
+    o32 = _with_perturbed(o32, lambda seed: _oracle("gan2", sds, lr, batch, noise, masks, torch.float32, perturb=seed)[0])
+    check("gan2 phraseZ discriminator loss", meters["z_phrase"].val, o["phrase_loss"])
+    check("gan2 barZ discriminator loss", meters["z_bar"].val, o["bar_loss"])
+    check("gan2 bar discriminator loss", meters["discriminator"].val, o["note_loss"])
+    check("gan2 feature discriminator loss", meters["discriminator_feature"].val, o["feature_loss"])
+    check("gan2 generator loss", meters["generator"].val, o["generator_loss"])
+    check("gan2 returned sample", out, o["gen"][:3], max(TOL, 2e-3))
+    for net, key in (("z_discriminator_phrase", "grad_z_phrase"), ("z_discriminator_bar", "grad_z_bar"),
+                     ("discriminator", "grad_discriminator"), ("discriminator_feature", "grad_discriminator_feature"),
+                     ("generator", "grad_generator")):
+        _compare_net("gan2 " + net, getattr(agent, net), grads[net], o[key], o32[key], osd[net], sds[net], lr)
+    pop_margins("barGen_with_gan2 iteration vs fp64 oracle", 10)
+    assert set(grads) == {"generator", "discriminator", "discriminator_feature", "z_discriminator_bar", "z_discriminator_phrase"}
+    assert all(n.opt.step_count == 1 for n in agent.nets.values())
+    _bn_stats("gan2", agent.discriminator, osd["discriminator"], 0)      # eval mode: the statistics never move
 
 
 def test_train_gan_iteration_bf16_storage(tmp_path, monkeypatch):

@@ -365,6 +365,57 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+@pytest.mark.parametrize("fam", ["x3", "bf16"])
+def test_split_k_workspace_is_caller_owned(fam):
+    """``size_t mgvae_<op>_workspace(desc, mode)`` + ``ws, ws_bytes`` in the entry points, no allocation
+    inside the library.  On a deep, under-filled layer (512 -> 512, 3x3 on a 6x4 map: the geometry the deterministic split-K
+    exists for) the query asks for a workspace; with every split forced in turn the result must be the same to fp32 rounding
+    with a full, a half-sized (the split shrinks to fit), a null (plain launch) workspace, a filled-chip geometry asks for
+    none, and nothing is written past ``ws_bytes``."""
+    import os
+    from hipops import _native as nat
+    L = nat.lib()
+    N, C, H, W_, k = 8, 512, 6, 4, 3
+    d = nat.ConvDesc(N, C, H, W_, C, H, W_, k, k, 1, 1, 1, 1, C, 0, C, 0, 0, 0.0)
+    q = getattr(L, "mgvae_conv2d_nhwc_%s_workspace" % fam)
+    need = [int(q(ctypes.byref(d), m)) for m in (0, 1, 2)]
+    rows = N * H * W_
+    assert need[0] == need[1] == 4 * rows * C * 4 and need[2] == 0, need
+    big = nat.ConvDesc(64, 64, 192, 30, 64, 192, 30, 3, 3, 1, 1, 1, 1, 64, 0, 64, 0, 0, 0.0)
+    assert int(q(ctypes.byref(big), 0)) == 0 and int(q(ctypes.byref(big), 1)) == 0        # 5760 workgroups: never split
+    torch.manual_seed(3)
+    x = torch.randn(N, C, H, W_).relu_(); w = torch.randn(C, C, k, k) * 0.05
+    yr = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dt = torch.float32 if fam == "x3" else torch.bfloat16
+    xd = cl(x).to(dt); wd = cl(w)
+    planes = 3 if fam == "x3" else 1
+    wk = torch.empty(planes * w.numel(), device=dev, dtype=torch.bfloat16); wt = torch.empty_like(wk)
+    pack = L.mgvae_pack_conv_weights_x3 if fam == "x3" else L.mgvae_pack_conv_weights_bf16
+    assert pack(vp(wd), vp(wk), vp(wt), C, k * k, C, stream()) == 0
+    fwd = getattr(L, "mgvae_conv2d_nhwc_%s_fwd" % fam)
+    guard = 4096
+    ws = torch.full((need[0] + guard,), 0x5A, device=dev, dtype=torch.uint8)
+    tol = 2e-5 if fam == "x3" else 2e-2
+    outs = []
+    try:
+        for split in (1, 2, 4):
+            for nbytes in (need[0], need[0] // 2, 0):
+                os.environ["MGVAE_X3_FORCE" if fam == "x3" else "MGVAE_BF16_FORCE"] = "0,%d" % split
+                y = cl(torch.zeros(N, C, H, W_)).to(dt)
+                ws.fill_(0x5A)
+                assert fwd(ctypes.byref(d), vp(xd), vp(wk), None, vp(y), None, vp(ws) if nbytes else None, nbytes, stream()) == 0
+                torch.cuda.synchronize()
+                assert bool((ws[nbytes:] == 0x5A).all()), "the library wrote past ws_bytes (split %d, %d bytes)" % (split, nbytes)
+                used = bool((ws[:max(nbytes, 1)] != 0x5A).any()) if nbytes else False
+                assert used == (split > 1 and nbytes > 0), (split, nbytes, used)
+                assert _rel(y, yr) <= tol, (split, nbytes, _rel(y, yr))
+                outs.append(y.float().cpu())
+    finally:
+        os.environ.pop("MGVAE_X3_FORCE", None); os.environ.pop("MGVAE_BF16_FORCE", None)
+    # deterministic: the same split and workspace size twice gives the same bits (no atomics in the forward-like products)
+    assert all(float((o - outs[0]).abs().max()) <= tol * float(outs[0].abs().max()) for o in outs)
+
+
 @pytest.mark.parametrize("g", GEOMS, ids=lambda g: "x".join(map(str, g)))
 def test_nhwc_x3_conv_three_products_are_fp32_grade(g):
     """fp32-storage family on the bf16 matrix pipe (csrc/conv_nhwc_x3.inc): every fp32 operand enters as three bf16 parts,
@@ -393,11 +444,11 @@ def test_nhwc_x3_conv_three_products_are_fp32_grade(g):
     d = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, s, s, p, p, Cx, 0, Cy, 0, 0, 0.0)
     got, ref = {}, {}
     y = cl(torch.zeros(N, Cy, OH, OW)); y0 = cl(torch.zeros(N, Cy, OH, OW))
-    assert L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), vp(b.to(dev)), vp(y), None, stream()) == 0
+    assert L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), vp(b.to(dev)), vp(y), None, None, 0, stream()) == 0
     assert L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d), vp(xd), vp(wd), vp(b.to(dev)), vp(y0), None, stream()) == 0
     got["fwd"], ref["fwd"] = _rel(y, yr), _rel(y0, yr)
     dx = cl(torch.zeros(N, Cx, H, W_)); dx0 = cl(torch.zeros(N, Cx, H, W_))
-    assert L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(dyd), vp(wt3), None, vp(dx), None, stream()) == 0
+    assert L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(dyd), vp(wt3), None, vp(dx), None, None, 0, stream()) == 0
     assert L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), vp(dyd), vp(wd), None, vp(dx0), None, stream()) == 0
     got["dx"], ref["dx"] = _rel(dx, xr.grad), _rel(dx0, xr.grad)
     dw = cl(torch.zeros(Cy, Cx, k, k)); dw0 = cl(torch.zeros(Cy, Cx, k, k))
@@ -415,7 +466,7 @@ def test_nhwc_x3_conv_three_products_are_fp32_grade(g):
     d2 = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, s, s, p, p, Cx + 8, 4, Cy + 4, 4, 1, 0.0)
     wide_y = cl(torch.zeros(N, Cy + 4, OH, OW)); wide_y[:, 4:] = dyd
     wide_x = cl(torch.full((N, Cx + 8, H, W_), 7.0))
-    assert L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d2), vp(wide_y), vp(wt3), vp(bt.to(dev)), vp(wide_x), None, stream()) == 0
+    assert L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d2), vp(wide_y), vp(wt3), vp(bt.to(dev)), vp(wide_x), None, None, 0, stream()) == 0
     check("x3 convT+bias+relu into a slice %s" % (g,), wide_x[:, 4:4 + Cx], tr, 2e-5)
     assert (wide_x[:, :4] == 7).all() and (wide_x[:, 4 + Cx:] == 7).all()
 
@@ -452,10 +503,10 @@ def test_nhwc_bf16_conv_three_products(g):
     assert torch.equal(wt.view(Cx, k, k, Cy).permute(3, 0, 1, 2).cpu(), w)
     d = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, s, s, p, p, Cx, 0, Cy, 0, 0, 0.0)
     yd = clb(torch.zeros(N, Cy, OH, OW).bfloat16())
-    assert L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), vp(xd), vp(wk), vp(b.to(dev)), vp(yd), None, stream()) == 0
+    assert L.mgvae_conv2d_nhwc_bf16_fwd(ctypes.byref(d), vp(xd), vp(wk), vp(b.to(dev)), vp(yd), None, None, 0, stream()) == 0
     check("nhwc bf16 fwd %s" % (g,), yd.float(), yr, 4e-3)
     dx = clb(torch.zeros(N, Cx, H, W_).bfloat16())
-    assert L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), vp(dyd), vp(wt), None, vp(dx), None, stream()) == 0
+    assert L.mgvae_conv2d_nhwc_bf16_bwd_data(ctypes.byref(d), vp(dyd), vp(wt), None, vp(dx), None, None, 0, stream()) == 0
     check("nhwc bf16 dx %s" % (g,), dx.float(), xr.grad, 4e-3)
     dw = cl(torch.ones(Cy, Cx, k, k))
     assert L.mgvae_conv2d_nhwc_bf16_bwd_weight(ctypes.byref(d), vp(xd), vp(dyd), vp(dw), stream()) == 0

@@ -159,3 +159,64 @@ def test_oracle_agent_iterations_are_consistent_with_the_pinned_pieces():
         first = R.generator_sample(sds["generator"], lat[0][0], torch.zeros(1, 1, 96, 60), torch.zeros(1, 1, 384, 60), torch.tensor([330]))
     assert torch.equal(raw[0], first) and torch.equal(roll[0, :96], (first > 0.3).float().view(96, 60))
     assert tuple(roll.shape) == (1, 384, 60) and set(roll.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_oracle_bargen_and_gan2_iterations_are_consistent_with_the_pinned_pieces():
+    """the two restatements added in round 3 (agent/barGen.py:254-327, agent/barGen_with_gan2.py:345-404 + :468-519), tied
+    to the pinned pieces the same way: losses recomposed from restate.* forwards at the initial weights, the D7 consequence
+    (no decoder gradient in barGen's adversarial generator block), BatchNorm pass counts (3 train-mode passes in barGen,
+    none in barGen_with_gan2, whose bar discriminator is always in eval mode), who steps."""
+    from oracle import steps as S
+    B, lr = 2, 0.002
+    sds = {"generator": W.make_state_dict(W.manifest_generator(), 0, "wc"),
+           "discriminator": W.make_state_dict(W.manifest_bar_discriminator(), 0, "wc"),
+           "discriminator_feature": W.make_state_dict(W.manifest_bar_feature_discriminator(), 0, "wc"),
+           "z_bar": W.make_state_dict(W.manifest_z_discriminator(), 1, "wc"),
+           "z_phrase": W.make_state_dict(W.manifest_z_discriminator(), 2, "wc")}
+    batch = W.make_inputs(B, seed=33)
+    note, pre_note, phrase, pos = batch
+    g = torch.Generator().manual_seed(18)
+    masks = [(torch.rand(B, 1152, generator=g) >= 0.3).float() / 0.7 for _ in range(2)]
+    ones, zeros = torch.ones(B), torch.zeros(B)
+    # ---- agent/barGen.py adversarial iteration
+    noise = [torch.randn(B, 1152, generator=g), torch.randn(2 * B, 1152, generator=g)]
+    osd = {n: S.leaf_copy(sd, torch.float32) for n, sd in sds.items()}
+    opts = {"gen2": S.AdamState(osd["generator"], lr), "discriminator": S.AdamState(osd["discriminator"], lr),
+            "z_bar": S.AdamState(osd["z_bar"], lr), "z_phrase": S.AdamState(osd["z_phrase"], lr)}
+    o = S.bargen_iteration(osd["generator"], osd["discriminator"], osd["z_bar"], osd["z_phrase"], opts, batch, noise, masks, True)
+    with torch.no_grad():
+        gen, z, pre_z, pf = R.generator_train(sds["generator"], note, pre_note, phrase, pos, True, masks)
+        want_phrase = R.dloss(R.z_discriminator(sds["z_phrase"], "", pf).view(-1), ones) + \
+            R.dloss(R.z_discriminator(sds["z_phrase"], "", noise[0]).view(-1), zeros)
+        want_bar = R.dloss(R.z_discriminator(sds["z_bar"], "", z).view(-1), ones) + R.dloss(R.z_discriminator(sds["z_bar"], "", pre_z).view(-1), ones) + \
+            R.dloss(R.z_discriminator(sds["z_bar"], "", noise[1]).view(-1), torch.zeros(2 * B))
+    assert abs(o["phrase_loss"].item() - want_phrase.item()) <= 1e-6 * abs(want_phrase.item())
+    assert abs(o["bar_loss"].item() - want_bar.item()) <= 1e-6 * abs(want_bar.item())
+    assert int(osd["discriminator"]["chord.batch_norm1.num_batches_tracked"]) == 3
+    assert all(opts[n].t == 1 for n in opts)
+    gg = o["grad_generator"]
+    assert all(v is None for k, v in gg.items() if k.startswith("decoder."))           # D7 + the 0.3 threshold
+    assert gg["encoder.linear.weight"].abs().max().item() > 0 and gg["phrase_encoder.phrase_encoder.linear.weight"].abs().max().item() > 0
+    same = torch.equal(osd["generator"]["decoder.fit1.weight"].detach(), sds["generator"]["decoder.fit1.weight"])
+    assert same, "the decoder must not move in barGen's adversarial generator block"
+    assert not torch.equal(osd["discriminator"]["linear.weight"].detach(), sds["discriminator"]["linear.weight"])
+    # ---- agent/barGen_with_gan2.py iteration
+    noise = [torch.randn(B, 1152, generator=g) for _ in range(2)] + [torch.randn(B, 1152, generator=g) * 1.5]
+    osd = {n: S.leaf_copy(sd, torch.float32) for n, sd in sds.items()}
+    opts = {n: S.AdamState(osd[n], lr) for n in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+    o = S.gan2_iteration(osd["generator"], osd["discriminator"], osd["discriminator_feature"], osd["z_bar"], osd["z_phrase"],
+                         opts, batch, noise, masks)
+    with torch.no_grad():
+        gen, z, pre_z, pf, gen_z = R.generator_gan(sds["generator"], note, pre_note, phrase, pos, True, True, masks)
+        fake = torch.cat((pre_note, (gen > 0.3).float()), dim=2)
+        want_note = R.dloss(R.bar_discriminator(dict(sds["discriminator"]), "", torch.cat((pre_note, note), dim=2), train=False).view(-1), zeros) + \
+            R.dloss(R.bar_discriminator(dict(sds["discriminator"]), "", fake, train=False).view(-1), ones)
+        want_feat = R.dloss(R.bar_feature_discriminator(sds["discriminator_feature"], "", z).view(-1), zeros) + \
+            R.dloss(R.bar_feature_discriminator(sds["discriminator_feature"], "", gen_z).view(-1), ones)
+    assert abs(o["note_loss"].item() - want_note.item()) <= 1e-6 * abs(want_note.item())
+    assert abs(o["feature_loss"].item() - want_feat.item()) <= 1e-6 * abs(want_feat.item())
+    assert int(osd["discriminator"]["chord.batch_norm1.num_batches_tracked"]) == 0       # eval mode throughout
+    assert torch.equal(osd["discriminator"]["chord.batch_norm1.running_mean"], sds["discriminator"]["chord.batch_norm1.running_mean"])
+    assert all(opts[n].t == 1 for n in opts) and torch.isfinite(o["generator_loss"])
+    gg = o["grad_generator"]
+    assert gg["decoder.fit1.weight"].abs().max().item() > 0 and gg["decoder.layers.0.bn1.weight"] is None       # recon term reaches the decoder; D5

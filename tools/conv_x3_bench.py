@@ -21,6 +21,8 @@ CASES = [  # name, N, Cx, H, W, Cy, k, s, p
     ("1x1 2048->1024 6x3", B, 2048, 6, 3, 1024, 1, 1, 0), ("1x1 128->64 96x60", B, 128, 96, 60, 64, 1, 1, 0),
 ]
 def vp(t): return ctypes.c_void_p(t.data_ptr())
+WS = torch.empty(512 << 20, device=dev, dtype=torch.uint8)      # caller-owned split-K workspace (include/mgvae.h), ample for every case
+WS_P, WS_N = vp(WS), WS.numel()
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 def timeit(fn):
     for _ in range(3): assert fn() == 0
@@ -40,8 +42,8 @@ for name, N, Cx, H, W, Cy, k, st, p in CASES:
     dw = torch.zeros(Cy, k * k, Cx, device=dev)
     d = nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k, k, st, st, p, p, Cx, 0, Cy, 0, 0, 0.0)
     flops = 2.0*N*OH*OW*Cy*Cx*k*k
-    b = [timeit(lambda: L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(x), vp(wk3), None, vp(y), None, s)),
-         timeit(lambda: L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(y), vp(wt3), None, vp(x), None, s)),
+    b = [timeit(lambda: L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(x), vp(wk3), None, vp(y), None, WS_P, WS_N, s)),
+         timeit(lambda: L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(y), vp(wt3), None, vp(x), None, WS_P, WS_N, s)),
          timeit(lambda: L.mgvae_conv2d_nhwc_x3_bwd_weight(ctypes.byref(d), vp(x), vp(y), vp(dw), s))]
     a = [timeit(lambda: L.mgvae_conv2d_nhwc_fwd(ctypes.byref(d), vp(x), vp(w), None, vp(y), None, s)),
          timeit(lambda: L.mgvae_conv2d_nhwc_bwd_data(ctypes.byref(d), vp(y), vp(w), None, vp(x), None, s)),

@@ -9,6 +9,8 @@ from hipops import _native as nat
 L = nat.lib()
 dev = 'cuda'
 def vp(t): return ctypes.c_void_p(t.data_ptr())
+WS = torch.empty(512 << 20, device=dev, dtype=torch.uint8)      # caller-owned split-K workspace (include/mgvae.h), ample for every case
+WS_P, WS_N = vp(WS), WS.numel()
 def cl(t): return t.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
 s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 GEOMS = [(4, 64, 192, 30, 64, 3, 1, 1), (4, 64, 192, 30, 128, 3, 2, 1), (4, 128, 96, 15, 128, 3, 1, 1), (4, 128, 96, 15, 256, 3, 2, 1),
@@ -29,8 +31,8 @@ for (N, Cx, H, W, Cy, k, st, p) in GEOMS:
     for tile, split in itertools.product(range(12), (1, 2, 5)):      # split: wgrad pixel splits AND the forward / data gradient's deterministic split-K
         os.environ["MGVAE_X3_FORCE"] = "%d,%d" % (tile, split)
         yd = cl(torch.zeros(N, Cy, OH, OW)); dx = cl(torch.zeros(N, Cx, H, W)); dw = cl(torch.zeros(Cy, Cx, k, k))
-        rc = [L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), None, vp(yd), None, s),
-              L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(dyd), vp(wt3), None, vp(dx), None, s),
+        rc = [L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), None, vp(yd), None, WS_P, WS_N, s),
+              L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(dyd), vp(wt3), None, vp(dx), None, WS_P, WS_N, s),
               L.mgvae_conv2d_nhwc_x3_bwd_weight(ctypes.byref(d), vp(xd), vp(dyd), vp(dw), s)]
         torch.cuda.synchronize()
         e = [float((a.double().cpu() - b).abs().max() / b.abs().max()) for a, b in ((yd, yr.detach()), (dx, xr.grad), (dw, wr.grad))]
