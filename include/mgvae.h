@@ -348,6 +348,29 @@ int mgvae_f32_to_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 int mgvae_bf16_to_f32(const void* src_bf16, float* dst, size_t n, void* stream);
 int mgvae_bf16_rows_sum(const void* rows_bf16, void* dst_bf16, int R, size_t n, void* stream);
 
+/* ---- launch chains (round 3; csrc/chain.hip) -----------------------------------------------------------------------
+ * One call enqueues a whole sequence of the entry points above -- a block's forward or backward -- so that the host layer
+ * pays one foreign call and one autograd node per block instead of one per launch (the reference's block boundaries:
+ * graph/encodingBlock.py:87-100,118-126; graph/decoder.py:91-109,135-154).  Call k invokes entry point `fn` (an id from
+ * mgvae_chain_fn_id(name); ids are positions in the sorted list of int-returning entry points, mgvae_chain_fn_count() of
+ * them) with `nargs` arguments read from the 8-byte words words[first .. first + nargs): pointers, size_t, long and
+ * uint64_t as the 64-bit word, int as its low 32 bits, float as the IEEE bits in its low 32 bits, double as the word's
+ * bits; a struct-pointer argument points wherever the caller keeps the struct (usually further words of the same array).
+ * Every entry point takes its stream as an argument, so one chain may span several streams; mgvae_stream_fork orders
+ * them.  Stops at the first call that fails: returns its code and, when `failed` is not null, stores its index there (-1
+ * if none).  Same kernels, tuner decisions, results and stream order as issuing the calls one by one.                       */
+typedef struct MgvaeChainCall { int32_t fn, nargs, first, reserved; } MgvaeChainCall;
+int mgvae_chain_fn_count(void);
+int mgvae_chain_fn_id(const char* name);
+int mgvae_chain_run(const MgvaeChainCall* calls, int ncalls, const uint64_t* words, int* failed);
+/* stream `to` waits for everything enqueued on stream `from` so far (hipEventRecord + hipStreamWaitEvent on a library-owned
+ * event per ordered stream pair): how a chain forks a weight gradient onto a side stream and joins it again             */
+int mgvae_stream_fork(void* from, void* to);
+/* dst += src over n elements of the channels-last storage type (0 fp32, 1 bf16; n a multiple of 4): the sum of the two
+ * gradient contributions of a tensor that feeds two consumers inside one chained block (residual input, the twin
+ * transposed convs of a decoder block)                                                                                    */
+int mgvae_add_inplace_typed(void* dst, const void* src, size_t n, int storage, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ----------------------------------------
  * When enabled, every mgvae_conv2d_* launch is bracketed by hipEvents on its stream and
  * its algorithmic FLOPs are recorded.  mgvae_prof_collect synchronises the events and

@@ -66,6 +66,39 @@ extern "C" int mgvae_add_inplace(float* dst, const float* src, size_t n, void* s
     return MGVAE_OK;
 }
 
+__global__ __launch_bounds__(256) void add_inplace_bf16_kernel(__bf16* __restrict__ dst, const __bf16* __restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        uint2 a = reinterpret_cast<const uint2*>(dst)[i];
+        const uint2 b = reinterpret_cast<const uint2*>(src)[i];
+        auto add2 = [](unsigned x, unsigned y) {            // two packed bf16: add in fp32, round to nearest even
+            const float lo = __uint_as_float(x << 16) + __uint_as_float(y << 16);
+            const float hi = __uint_as_float(x & 0xffff0000u) + __uint_as_float(y & 0xffff0000u);
+            auto rne = [](float f) { unsigned u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+            return rne(lo) | (rne(hi) << 16);
+        };
+        a.x = add2(a.x, b.x); a.y = add2(a.y, b.y);
+        reinterpret_cast<uint2*>(dst)[i] = a;
+    }
+}
+__global__ __launch_bounds__(256) void add_inplace_f4_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 a = dst[i]; const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+}
+extern "C" int mgvae_add_inplace_typed(void* dst, const void* src, size_t n, int storage, void* stream) {
+    if (!dst || !src || n == 0 || (n & 3) || (storage != 0 && storage != 1)) return MGVAE_EINVAL;
+    if (storage == 1)
+        hipLaunchKernelGGL(add_inplace_bf16_kernel, dim3(grid_for(n / 4, 4096)), dim3(256), 0, as_stream(stream),
+                           static_cast<__bf16*>(dst), static_cast<const __bf16*>(src), n / 4);
+    else
+        hipLaunchKernelGGL(add_inplace_f4_kernel, dim3(grid_for(n / 4, 4096)), dim3(256), 0, as_stream(stream),
+                           static_cast<float4*>(dst), static_cast<const float4*>(src), n / 4);
+    MGVAE_CHECK_LAUNCH();
+    return MGVAE_OK;
+}
+
 __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                   float* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a[i] * b[i];

@@ -8,6 +8,7 @@ import os
 import torch
 from torch import nn
 
+from hipops import blocks as HB
 from hipops import functional as HF
 from graph.cbam import CBAM
 from graph.layers import Conv2d, ConvTranspose2d, Embedding, InstanceNorm2d, Linear
@@ -68,6 +69,8 @@ class DeConvModule(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
+        if self.channels_last and out is None and HB.usable(x):
+            return HB.deconv_block(x, self, False)
         co = self.out_channel
         n, _, h, w = x.shape
         cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w, x)
@@ -98,6 +101,8 @@ class DeConvPitchPadding(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
+        if self.channels_last and out is None and HB.usable(x):
+            return HB.deconv_block(x, self, True)
         co = self.out_channel
         n, _, h, w = x.shape
         cat = _new(self.channels_last, n, 2 * co, 2 * h, 2 * w + 1, x)
@@ -139,7 +144,8 @@ class Decoder(nn.Module):
         m = self._drop_masks[i] if self._drop_masks is not None else None
         return HF.dropout(t, self.dropout_p, self.training, mask=m)
 
-    def forward(self, z, pre_z, phrase_feature, position):
+    def head(self, z, pre_z, phrase_feature, position):
+        """graph/decoder.py:192-205: the two Linear + ReLU + Dropout branches and their concat -> [n, 2304, 1, 1]"""
         n, dev = z.shape[0], z.device
         new = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
         # cat(phrase_feature, embedding(position)) -> Linear -> ReLU -> Dropout
@@ -155,16 +161,29 @@ class Decoder(nn.Module):
         xbuf = new(n, 2304)
         xa = HF.copy_into(bf, xbuf[:, :1152])
         xb = HF.copy_into(pf, xbuf[:, 1152:])
-        x = HF.join(xbuf, xa, xb).view(n, 2304, 1, 1)
-        cat = new(n, 2048, 6, 3)
+        return HF.join(xbuf, xa, xb).view(n, 2304, 1, 1)
+
+    def stems(self, x):
+        """graph/decoder.py:207-211: the two stems side by side -> [n, 2048, 6, 3] (NCHW)"""
+        n = x.shape[0]
+        cat = torch.empty((n, 2048, 6, 3), device=x.device, dtype=torch.float32)
         with HF.forked_branch(x, cat):            # the two stems are independent until fit1
             time = self.time(x, out=cat[:, 1024:])
         pitch = self.pitch(x, out=cat[:, :1024])
         HF.join_side_streams(slot=0)
-        o = HF.join(cat, pitch, time)
+        return HF.join(cat, pitch, time)
+
+    def fit_stage(self, o):
+        """graph/decoder.py:213-215: fit1 -> InstanceNorm -> +CBAM -> ReLU (``o`` in the island's layout)"""
+        if self.channels_last and HB.usable(o):
+            return HB.conv_norm_cbam_block(o, self.fit1, self.bn, self.cbam)
+        return self.cbam.fused_norm(self.fit1(o), self.bn, 1, act=HF.ACT_RELU, channels_last=self.channels_last)
+
+    def forward(self, z, pre_z, phrase_feature, position):
+        o = self.stems(self.head(z, pre_z, phrase_feature, position))
         if self.channels_last:
             o = HF.to_channels_last(o)
-        o = self.cbam.fused_norm(self.fit1(o), self.bn, 1, act=HF.ACT_RELU, channels_last=self.channels_last)
+        o = self.fit_stage(o)
         for blk in self.layers:
             o = blk(o)
         if self.channels_last:

@@ -37,13 +37,17 @@ class _ConvTrunk(nn.Module):
         self.last_kl = None
         self.apply(weights_init)
 
-    def features(self, x):
-        """the conv trunk up to the pooled [n, 1024] features (everything but the final Linear)"""
+    def stem_cat(self, x):
+        """the two stems side by side: [n, 1, h, w] -> [n, 64, h/2, w/2] (NCHW; graph/encoder.py:27-29)"""
         n, _, h, w = x.shape
         cat = torch.empty((n, 64, h // 2, w // 2), device=x.device, dtype=torch.float32)
         pitch = self.pitch_time(x, out=cat[:, :32])
         time = self.time_pitch(x, out=cat[:, 32:])
-        o = HF.join(cat, pitch, time)
+        return HF.join(cat, pitch, time)
+
+    def features(self, x):
+        """the conv trunk up to the pooled [n, 1024] features (everything but the final Linear)"""
+        o = self.stem_cat(x)
         if self.channels_last:
             o = HF.to_channels_last(o)
         # when the gradient of this tensor exists, every parameter gradient of ``layers`` and ``linear`` is enqueued:

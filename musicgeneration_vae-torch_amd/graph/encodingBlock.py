@@ -5,6 +5,7 @@ epilogue -> InstanceNorm -> fused CBAM + residual + activation.  ``out=`` lets a
 write its result straight into a channel slice of its consumer's concat buffer."""
 from torch import nn
 
+from hipops import blocks as HB
 from hipops import functional as HF
 from graph.cbam import CBAM
 from graph.layers import Conv2d, InstanceNorm2d
@@ -56,6 +57,8 @@ class ResidualModule(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
+        if self.channels_last and out is None and HB.usable(x):
+            return HB.residual_block(x, self.conv1, self.conv2, self.bn, self.cbam)      # one node, one launch chain
         # conv1's ReLU gradient is applied by conv2's data gradient (conv2 is the only consumer of relu(conv1(x)))
         o = self.conv2(self.conv1(x, act=HF.ACT_RELU, defer_act_grad=True), in_act=(HF.ACT_RELU, 0.0))
         return self.cbam.fused_norm(o, self.bn, 2, res=x, act=HF.ACT_RELU, out=out, channels_last=self.channels_last)
@@ -73,4 +76,6 @@ class PoolingModule(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
+        if self.channels_last and out is None and HB.usable(x):
+            return HB.conv_norm_cbam_block(x, self.conv, self.bn, self.cbam)
         return self.cbam.fused_norm(self.conv(x), self.bn, 1, act=HF.ACT_RELU, out=out, channels_last=self.channels_last)

@@ -26,6 +26,11 @@ class ActMask(ctypes.Structure):
                 ("slope", ctypes.c_float)]
 
 
+class ChainCall(ctypes.Structure):
+    """MgvaeChainCall (include/mgvae.h)"""
+    _fields_ = [("fn", ctypes.c_int32), ("nargs", ctypes.c_int32), ("first", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class ProfRec(ctypes.Structure):  # noqa: E302
     _fields_ = [("kind", ctypes.c_int32), ("tile", ctypes.c_int32), ("launches", ctypes.c_int32),
                 ("ms", ctypes.c_double), ("flops", ctypes.c_double)]
@@ -110,6 +115,11 @@ SIGNATURES = {
     "mgvae_f32_to_bf16": (c_int, [P, P, c_size_t, P]),
     "mgvae_bf16_to_f32": (c_int, [P, P, c_size_t, P]),
     "mgvae_bf16_rows_sum": (c_int, [P, P, c_int, c_size_t, P]),
+    "mgvae_chain_fn_count": (c_int, []),
+    "mgvae_chain_fn_id": (c_int, [ctypes.c_char_p]),
+    "mgvae_chain_run": (c_int, [ctypes.POINTER(ChainCall), c_int, P, ctypes.POINTER(c_int)]),
+    "mgvae_stream_fork": (c_int, [P, P]),
+    "mgvae_add_inplace_typed": (c_int, [P, P, c_size_t, c_int, P]),
     "mgvae_prof_enable": (c_int, [c_int]),
     "mgvae_prof_collect": (c_int, [ctypes.POINTER(ProfRec), c_int]),
     "mgvae_prof_detail": (c_int, [ctypes.c_char_p]),

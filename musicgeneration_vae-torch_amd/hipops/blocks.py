@@ -1,0 +1,488 @@
+"""Whole blocks of the channels-last island as ONE autograd node and ONE foreign call per direction.
+
+The reference's block boundaries -- ResidualModule / PoolingModule (graph/encodingBlock.py:87-100,118-126), DeConvModule /
+DeConvPitchPadding (graph/decoder.py:91-109,135-154), and the decoder's fit1 + InstanceNorm + CBAM (graph/decoder.py:213-215)
+-- are where this build cuts its launch chains (hipops/chain.py, csrc/chain.hip).  The forward of a block is the same list
+of entry points, in the same order, that the per-op autograd functions of hipops/functional.py issue; so is the backward,
+with three differences that autograd used to supply from outside: the two gradient contributions of a tensor with two
+consumers inside a block (the residual input; the input of a decoder block's twin transposed convs) are summed by
+mgvae_add_inplace_typed instead of an ATen add, the weight gradients are forked onto the side stream by mgvae_stream_fork
+instead of torch stream contexts, and intermediate gradients never become autograd tensors.
+
+``MGVAE_CHAIN=0`` switches the island back to one node per op (tests run both; tools/ab_env.sh measures the difference).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _native as nat
+from . import functional as HF
+from .chain import Chain
+
+ENABLED = os.environ.get("MGVAE_CHAIN", "1") != "0"
+_chains = {}
+
+
+def usable(x):
+    """chains cover the channels-last island in its three engines; anything else keeps the per-op path"""
+    if not ENABLED or not HF.DEFER_ACT_GRAD or not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    return HF.cl_pitch(x) is not None
+
+
+def _engine(x, *channels):
+    if x.dtype == torch.bfloat16:
+        return "bf16"
+    if HF.FP32_ENGINE == "x3" and all(c % 16 == 0 for c in channels):
+        return "x3"
+    return "f32"
+
+
+def _weights(eng, w):
+    """(forward operand, data-gradient operand) of conv weight ``w`` for the engine"""
+    if eng == "x3":
+        return HF._x3_weights(w)
+    if eng == "bf16":
+        return HF._bf16_weights(w)
+    return w, w
+
+
+def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, xct, yct, act=HF.ACT_NONE, slope=0.0):
+    return nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], xct, 0, yct, 0, act, slope)
+
+
+def _ws_bytes(eng, d, mode):
+    if eng == "f32":
+        return 0
+    fn = nat.lib().mgvae_conv2d_nhwc_x3_workspace if eng == "x3" else nat.lib().mgvae_conv2d_nhwc_bf16_workspace
+    return int(fn(ctypes.byref(d), mode))
+
+
+class _Emit:
+    """appends the conv entry points of one engine to a chain; tracks the largest split-K workspace any of them may use"""
+
+    def __init__(self, ch, eng, ws, st):
+        self.ch, self.eng, self.ws, self.st, self.ws_bytes = ch, eng, ws, st, 0
+
+    def _ws(self, d, mode):
+        n = _ws_bytes(self.eng, d, mode)
+        self.ws_bytes = max(self.ws_bytes, n)
+        return n
+
+    def fwd(self, d, x, wk, bias, y, mask=None):
+        """Y = conv(X) -- also the data gradient of a transposed conv"""
+        ref = self.ch.struct(d)
+        if self.eng == "f32":
+            self.ch.call("mgvae_conv2d_nhwc_fwd", ref, x, wk, bias, y, mask, self.st)
+        else:
+            n = self._ws(d, 0)
+            self.ch.call("mgvae_conv2d_nhwc_%s_fwd" % self.eng, ref, x, wk, bias, y, mask, self.ws if n else None, n, self.st)
+
+    def bwd_data(self, d, y, wt, bias, x, mask=None):
+        """X = conv_transpose(Y) -- the data gradient of a conv, and a transposed conv's forward"""
+        ref = self.ch.struct(d)
+        if self.eng == "f32":
+            self.ch.call("mgvae_conv2d_nhwc_bwd_data", ref, y, wt, bias, x, mask, self.st)
+        else:
+            n = self._ws(d, 1)
+            self.ch.call("mgvae_conv2d_nhwc_%s_bwd_data" % self.eng, ref, y, wt, bias, x, mask, self.ws if n else None, n, self.st)
+
+    def bwd_weight(self, d, x, y, dw, stream):
+        name = {"f32": "mgvae_conv2d_nhwc_bwd_weight", "x3": "mgvae_conv2d_nhwc_x3_bwd_weight",
+                "bf16": "mgvae_conv2d_nhwc_bf16_bwd_weight"}[self.eng]
+        self.ch.call(name, self.ch.struct(d), x, y, dw, stream)
+
+    def mask(self, src, ctot, act, slope=0.0):
+        return self.ch.struct(nat.ActMask(0, ctot, 0, act, slope), (("src", src),))
+
+
+def _new(n, c, h, w, like):
+    return HF.new_channels_last(n, c, h, w, like.device, like.dtype)
+
+
+def _f32(n, dev):
+    return torch.empty((n,), device=dev, dtype=torch.float32)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else 0
+
+
+def _main():
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _grad(p):
+    return HF.grad_slot(p) if (p is not None and p.requires_grad) else None
+
+
+def _side_for(n, trainable, need_dx, touched):
+    """the stream this backward's weight gradients run on: the side stream paired with the current one (and the
+    end-of-backward join armed, the tensors it reads marked for the allocator) when the batch is large enough for forking to
+    pay (hipops/functional.py: FORK_MIN_BATCH), else the current stream itself"""
+    cur_raw = _main()
+    if not (HF.FORK_WGRAD and n >= HF.FORK_MIN_BATCH and need_dx and trainable):
+        if HF._trunk_streams or HF._used_sides:
+            HF._ensure_join_callback()
+        return cur_raw, cur_raw
+    cur = torch.cuda.current_stream()
+    HF._wgrad_rr[0] += 1
+    slot = 2 + HF._wgrad_rr[0] % HF.WGRAD_STREAMS
+    side = HF.side_stream_of(cur, slot)
+    for t in touched:
+        if t is not None:
+            t.record_stream(side)
+    HF._used_sides[id(side)] = (side, slot, None if HF._shared_sides() else cur.cuda_stream)
+    HF._ensure_join_callback()
+    return cur_raw, side.cuda_stream
+
+
+def _dense_cl(dy, like, pitch):
+    """the incoming gradient as a channels-last tensor of ``like``'s storage type whose pixel pitch is ``pitch``"""
+    dy = HF._as_cl(dy, like)
+    if HF.cl_pitch(dy) != pitch:
+        dy = dy.contiguous(memory_format=HF.CL)
+        if HF.cl_pitch(dy) != pitch:
+            raise RuntimeError("block backward: gradient pitch %s does not match the output's %s" % (HF.cl_pitch(dy), pitch))
+    return dy
+
+
+# ============================================================================================== residual block
+class _ResidualFn(torch.autograd.Function):
+    """relu(x + CBAM(IN(conv2(relu(conv1(x)))))) -- graph/encodingBlock.py:87-100"""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, gamma, beta, ca1, ca2, sa, eps):
+        N, C, H, W = x.shape
+        xct = HF._need_cl(x, "residual block")
+        HF._cl_weight(w1, "residual block"); HF._cl_weight(w2, "residual block")
+        eng = _engine(x, C)
+        st = HF._store(x)
+        key = ("res-f", N, C, H, W, xct, eng, float(eps))
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            s_x, s_wk1, s_wk2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_y, s_save, s_ws, s_st = ch.slots(14)
+            em = _Emit(ch, eng, s_ws, s_st)
+            k, o, p = (3, 3), (1, 1), (1, 1)
+            em.fwd(_desc(N, C, H, W, C, H, W, k, o, p, xct, C, HF.ACT_RELU, 0.01), s_x, s_wk1, None, s_t1)
+            em.fwd(_desc(N, C, H, W, C, H, W, k, o, p, C, C), s_t1, s_wk2, None, s_t2)
+            ch.call("mgvae_norm_cbam_nhwc_fwd", s_t2, s_g, s_b, s_x, xct, 0, s_c1, s_c2, s_sa, s_y, s_save, N, C, H, W, C, 0,
+                    eps, 2, HF.ACT_RELU, 0.01, st, s_st)
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, int(nat.lib().mgvae_norm_cbam_nhwc_save_floats(N, C, H, W)))
+        ch, wsn, nsave = e
+        wk1, _ = _weights(eng, w1)
+        wk2, _ = _weights(eng, w2)
+        t1, t2, y = _new(N, C, H, W, x), _new(N, C, H, W, x), _new(N, C, H, W, x)
+        save = _f32(nsave, x.device)
+        ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
+        ch.run([x.data_ptr(), wk1.data_ptr(), wk2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ca1.data_ptr(), ca2.data_ptr(),
+                sa.data_ptr(), t1.data_ptr(), t2.data_ptr(), y.data_ptr(), save.data_ptr(), _ptr(ws), _main()])
+        ctx.save_for_backward(x, w1, w2, gamma, beta, ca1, ca2, sa, t1, t2, y, save)
+        ctx.cfg = (eng, xct, float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, gamma, beta, ca1, ca2, sa, t1, t2, y, save = ctx.saved_tensors
+        eng, xct, eps = ctx.cfg
+        N, C, H, W = x.shape
+        st = HF._store(x)
+        need_dx = ctx.needs_input_grad[0]
+        flags = tuple(bool(p.requires_grad) for p in (w1, w2, gamma, beta, ca1, ca2, sa))
+        key = ("res-b", N, C, H, W, xct, eng, need_dx, flags)
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            (s_x, s_t1, s_t2, s_y, s_dy, s_wt1, s_wt2, s_g, s_b, s_c1, s_c2, s_sa, s_save, s_dt2, s_dres, s_dt1, s_dx, s_dg, s_db,
+             s_dc1, s_dc2, s_dsa, s_dw1, s_dw2, s_scr, s_ws, s_st, s_side) = ch.slots(28)
+            em = _Emit(ch, eng, s_ws, s_st)
+            k, o, p = (3, 3), (1, 1), (1, 1)
+            ch.call("mgvae_norm_cbam_nhwc_bwd", s_t2, s_g, s_b, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt2, s_dres, s_dg, s_db,
+                    s_dc1, s_dc2, s_dsa, s_scr, N, C, H, W, C, 0, 2, HF.ACT_RELU, 0.01, st, s_st)
+            if flags[1]:
+                ch.call("mgvae_stream_fork", s_st, s_side)
+                em.bwd_weight(_desc(N, C, H, W, C, H, W, k, o, p, C, C), s_t1, s_dt2, s_dw2, s_side)
+            # conv2's data gradient applies relu'(t1) while storing (conv1 skipped its own activation-gradient pass)
+            em.bwd_data(_desc(N, C, H, W, C, H, W, k, o, p, C, C), s_dt2, s_wt2, None, s_dt1, em.mask(s_t1, C, HF.ACT_RELU))
+            if flags[0]:
+                ch.call("mgvae_stream_fork", s_st, s_side)
+                em.bwd_weight(_desc(N, C, H, W, C, H, W, k, o, p, xct, C), s_x, s_dt1, s_dw1, s_side)
+            if need_dx:
+                em.bwd_data(_desc(N, C, H, W, C, H, W, k, o, p, C, C), s_dt1, s_wt1, None, s_dx)
+                ch.call("mgvae_add_inplace_typed", s_dx, s_dres, N * C * H * W, st, s_st)
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, int(nat.lib().mgvae_norm_cbam_nhwc_scratch_floats(N, C, H, W)))
+        ch, wsn, nscr = e
+        dy = _dense_cl(dy, x, C)
+        _, wt1 = _weights(eng, w1)
+        _, wt2 = _weights(eng, w2)
+        dt2, dres, dt1 = _new(N, C, H, W, x), _new(N, C, H, W, x), _new(N, C, H, W, x)
+        dx = _new(N, C, H, W, x) if need_dx else None
+        scr = _f32(nscr, x.device)
+        ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
+        main, side = _side_for(N, flags[0] or flags[1], need_dx, (x, t1, dt2, dt1))
+        ch.run([x.data_ptr(), t1.data_ptr(), t2.data_ptr(), y.data_ptr(), dy.data_ptr(), wt1.data_ptr(), wt2.data_ptr(),
+                gamma.data_ptr(), beta.data_ptr(), ca1.data_ptr(), ca2.data_ptr(), sa.data_ptr(), save.data_ptr(), dt2.data_ptr(),
+                dres.data_ptr(), dt1.data_ptr(), _ptr(dx), _ptr(_grad(gamma)), _ptr(_grad(beta)), _ptr(_grad(ca1)), _ptr(_grad(ca2)),
+                _ptr(_grad(sa)), _ptr(_grad(w1)), _ptr(_grad(w2)), scr.data_ptr(), _ptr(ws), main, side])
+        return (dx,) + (None,) * 8
+
+
+def residual_block(x, conv1, conv2, bn, cbam):
+    for c in (conv1, conv2):
+        if (tuple(c.kernel_size), tuple(c.stride), tuple(c.padding)) != ((3, 3), (1, 1), (1, 1)) or c.bias is not None:
+            raise RuntimeError("residual_block: 3x3 stride-1 pad-1 convs without bias (graph/encodingBlock.py:74-77)")
+    ca, sa = cbam.channel_attention, cbam.spatial_attention
+    return _ResidualFn.apply(x, conv1.weight, conv2.weight, bn.weight, bn.bias, ca.conv1.weight, ca.conv2.weight, sa.conv.weight, bn.eps)
+
+
+# ============================================================================== conv -> InstanceNorm -> +CBAM -> ReLU
+class _ConvNormCbamFn(torch.autograd.Function):
+    """relu(u + CBAM(u)), u = IN(conv(x)): PoolingModule (3x3 s2, graph/encodingBlock.py:118-126) and the decoder's
+    fit1 stage (1x1, graph/decoder.py:213-215)"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, ca1, ca2, sa, eps, stride, pad):
+        N, Cx, H, W = x.shape
+        Cy, _, KH, KW = w.shape
+        xct = HF._need_cl(x, "conv block")
+        HF._cl_weight(w, "conv block")
+        OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+        OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        eng = _engine(x, Cx, Cy)
+        st = HF._store(x)
+        key = ("cnc-f", N, Cx, H, W, Cy, KH, KW, stride, pad, xct, eng, float(eps))
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            s_x, s_wk, s_g, s_b, s_c1, s_c2, s_sa, s_t, s_y, s_save, s_ws, s_st = ch.slots(12)
+            em = _Emit(ch, eng, s_ws, s_st)
+            em.fwd(_desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, Cy), s_x, s_wk, None, s_t)
+            ch.call("mgvae_norm_cbam_nhwc_fwd", s_t, s_g, s_b, None, 0, 0, s_c1, s_c2, s_sa, s_y, s_save, N, Cy, OH, OW, Cy, 0,
+                    eps, 1, HF.ACT_RELU, 0.01, st, s_st)
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, int(nat.lib().mgvae_norm_cbam_nhwc_save_floats(N, Cy, OH, OW)))
+        ch, wsn, nsave = e
+        wk, _ = _weights(eng, w)
+        t, y = _new(N, Cy, OH, OW, x), _new(N, Cy, OH, OW, x)
+        save = _f32(nsave, x.device)
+        ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
+        ch.run([x.data_ptr(), wk.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ca1.data_ptr(), ca2.data_ptr(), sa.data_ptr(),
+                t.data_ptr(), y.data_ptr(), save.data_ptr(), _ptr(ws), _main()])
+        ctx.save_for_backward(x, w, gamma, beta, ca1, ca2, sa, t, y, save)
+        ctx.cfg = (eng, xct, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, gamma, beta, ca1, ca2, sa, t, y, save = ctx.saved_tensors
+        eng, xct, stride, pad = ctx.cfg
+        N, Cx, H, W = x.shape
+        Cy, _, KH, KW = w.shape
+        _, _, OH, OW = y.shape
+        st = HF._store(x)
+        need_dx = ctx.needs_input_grad[0]
+        flags = tuple(bool(p.requires_grad) for p in (w, gamma, beta, ca1, ca2, sa))
+        key = ("cnc-b", N, Cx, H, W, Cy, KH, KW, stride, pad, xct, eng, need_dx, flags)
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            (s_x, s_t, s_y, s_dy, s_wt, s_g, s_b, s_c1, s_c2, s_sa, s_save, s_dt, s_dx, s_dg, s_db, s_dc1, s_dc2, s_dsa, s_dw,
+             s_scr, s_ws, s_st, s_side) = ch.slots(23)
+            em = _Emit(ch, eng, s_ws, s_st)
+            ch.call("mgvae_norm_cbam_nhwc_bwd", s_t, s_g, s_b, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt, None, s_dg, s_db, s_dc1,
+                    s_dc2, s_dsa, s_scr, N, Cy, OH, OW, Cy, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+            if flags[0]:
+                ch.call("mgvae_stream_fork", s_st, s_side)
+                em.bwd_weight(_desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, Cy), s_x, s_dt, s_dw, s_side)
+            if need_dx:
+                em.bwd_data(_desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, Cx, Cy), s_dt, s_wt, None, s_dx)
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, int(nat.lib().mgvae_norm_cbam_nhwc_scratch_floats(N, Cy, OH, OW)))
+        ch, wsn, nscr = e
+        dy = _dense_cl(dy, x, Cy)
+        _, wt = _weights(eng, w)
+        dt = _new(N, Cy, OH, OW, x)
+        dx = _new(N, Cx, H, W, x) if need_dx else None
+        scr = _f32(nscr, x.device)
+        ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
+        main, side = _side_for(N, flags[0], need_dx, (x, dt))
+        ch.run([x.data_ptr(), t.data_ptr(), y.data_ptr(), dy.data_ptr(), wt.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                ca1.data_ptr(), ca2.data_ptr(), sa.data_ptr(), save.data_ptr(), dt.data_ptr(), _ptr(dx), _ptr(_grad(gamma)),
+                _ptr(_grad(beta)), _ptr(_grad(ca1)), _ptr(_grad(ca2)), _ptr(_grad(sa)), _ptr(_grad(w)), scr.data_ptr(), _ptr(ws),
+                main, side])
+        return (dx,) + (None,) * 9
+
+
+def conv_norm_cbam_block(x, conv, bn, cbam):
+    if conv.bias is not None:
+        raise RuntimeError("conv_norm_cbam_block: the island's convs in front of an InstanceNorm carry no bias")
+    ca, sa = cbam.channel_attention, cbam.spatial_attention
+    return _ConvNormCbamFn.apply(x, conv.weight, bn.weight, bn.bias, ca.conv1.weight, ca.conv2.weight, sa.conv.weight, bn.eps,
+                                 tuple(conv.stride), tuple(conv.padding))
+
+
+# ================================================================================================ decoder blocks
+class _DeConvFn(torch.autograd.Function):
+    """DeConvModule (graph/decoder.py:91-109) and DeConvPitchPadding (:135-154; ``pp``): two transposed convs of the same
+    input -> InstanceNorm (+CBAM on branch a when ``pp``) -> ReLU, side by side in one buffer -> 1x1 conv -> InstanceNorm ->
+    +CBAM -> ReLU.  ``pp`` is literal about reference defect D5: ``bn2`` (ga == gb) normalises both branches."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, ga, bta, gb, btb, a_c1, a_c2, a_sa, w3, g3, b3, c1, c2, sa, eps, pp, geo_a, geo_b):
+        N, Ci, h, w = x.shape
+        xct = HF._need_cl(x, "decoder block")
+        Co = wa.shape[1]
+        for t in (wa, wb, w3):
+            HF._cl_weight(t, "decoder block")
+        (ka, sa_, pa, opa), (kb, sb_, pb, opb) = geo_a, geo_b
+        OH = (h - 1) * sa_[0] - 2 * pa[0] + ka[0] + opa[0]
+        OW = (w - 1) * sa_[1] - 2 * pa[1] + ka[1] + opa[1]
+        if (OH, OW) != ((h - 1) * sb_[0] - 2 * pb[0] + kb[0] + opb[0], (w - 1) * sb_[1] - 2 * pb[1] + kb[1] + opb[1]):
+            raise RuntimeError("decoder block: the two transposed convs disagree about the output size")
+        eng = _engine(x, Ci, Co)
+        st = HF._store(x)
+        esz = x.element_size()
+        L = nat.lib()
+        key = ("dec-f", N, Ci, h, w, Co, geo_a, geo_b, xct, eng, bool(pp), ba is not None, bb is not None, float(eps))
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            (s_x, s_wta, s_ba, s_wtb, s_bb, s_ga, s_bta, s_gb, s_btb, s_ac1, s_ac2, s_asa, s_wk3, s_g3, s_b3, s_c1, s_c2, s_sa, s_ta,
+             s_tb, s_cat, s_sta, s_stb, s_t3, s_y, s_save, s_ws, s_st) = ch.slots(28)
+            em = _Emit(ch, eng, s_ws, s_st)
+            # transposed conv = the stride-phase data-gradient kernel: image side X = the output (Cx = Co), feature side Y = x
+            em.bwd_data(_desc(N, Co, OH, OW, Ci, h, w, ka, sa_, pa, Co, xct), s_x, s_wta, s_ba if ba is not None else None, s_ta)
+            if pp:
+                ch.call("mgvae_norm_cbam_nhwc_fwd", s_ta, s_ga, s_bta, None, 0, 0, s_ac1, s_ac2, s_asa, s_cat, s_sta, N, Co, OH, OW,
+                        2 * Co, 0, eps, 1, HF.ACT_RELU, 0.01, st, s_st)
+            else:
+                ch.call("mgvae_instance_norm_nhwc_fwd", s_ta, s_ga, s_bta, s_cat, s_sta, N, Co, OH, OW, 2 * Co, 0, eps, HF.ACT_RELU,
+                        0.01, st, s_st)
+            em.bwd_data(_desc(N, Co, OH, OW, Ci, h, w, kb, sb_, pb, Co, xct), s_x, s_wtb, s_bb if bb is not None else None, s_tb)
+            ch.call("mgvae_instance_norm_nhwc_fwd", s_tb, s_gb, s_btb, s_cat + Co * esz, s_stb, N, Co, OH, OW, 2 * Co, 0, eps,
+                    HF.ACT_RELU, 0.01, st, s_st)
+            em.fwd(_desc(N, 2 * Co, OH, OW, Co, OH, OW, (1, 1), (1, 1), (0, 0), 2 * Co, Co), s_cat, s_wk3, None, s_t3)
+            ch.call("mgvae_norm_cbam_nhwc_fwd", s_t3, s_g3, s_b3, None, 0, 0, s_c1, s_c2, s_sa, s_y, s_save, N, Co, OH, OW, Co, 0,
+                    eps, 1, HF.ACT_RELU, 0.01, st, s_st)
+            n_nc = int(L.mgvae_norm_cbam_nhwc_save_floats(N, Co, OH, OW))
+            n_in = int(L.mgvae_instance_norm_nhwc_stats_floats(N, Co, OH, OW))
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, n_nc, n_in)
+        ch, wsn, n_nc, n_in = e
+        _, wta = _weights(eng, wa)
+        _, wtb = _weights(eng, wb)
+        wk3, _ = _weights(eng, w3)
+        ta, tb = _new(N, Co, OH, OW, x), _new(N, Co, OH, OW, x)
+        cat = _new(N, 2 * Co, OH, OW, x)
+        t3, y = _new(N, Co, OH, OW, x), _new(N, Co, OH, OW, x)
+        sta = _f32(n_nc if pp else n_in, x.device)
+        stb = _f32(n_in, x.device)
+        save = _f32(n_nc, x.device)
+        ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
+        ch.run([x.data_ptr(), wta.data_ptr(), _ptr(ba), wtb.data_ptr(), _ptr(bb), ga.data_ptr(), bta.data_ptr(), gb.data_ptr(),
+                btb.data_ptr(), _ptr(a_c1), _ptr(a_c2), _ptr(a_sa), wk3.data_ptr(), g3.data_ptr(), b3.data_ptr(), c1.data_ptr(),
+                c2.data_ptr(), sa.data_ptr(), ta.data_ptr(), tb.data_ptr(), cat.data_ptr(), sta.data_ptr(), stb.data_ptr(),
+                t3.data_ptr(), y.data_ptr(), save.data_ptr(), _ptr(ws), _main()])
+        ctx.save_for_backward(x, wa, ba, wb, bb, ga, bta, gb, btb, a_c1, a_c2, a_sa, w3, g3, b3, c1, c2, sa, ta, tb, cat, sta, stb,
+                              t3, y, save)
+        ctx.cfg = (eng, xct, bool(pp), geo_a, geo_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, wa, ba, wb, bb, ga, bta, gb, btb, a_c1, a_c2, a_sa, w3, g3, b3, c1, c2, sa, ta, tb, cat, sta, stb, t3, y,
+         save) = ctx.saved_tensors
+        eng, xct, pp, geo_a, geo_b = ctx.cfg
+        N, Ci, h, w = x.shape
+        _, Co, OH, OW = y.shape
+        (ka, sa_, pa, _), (kb, sb_, pb, _) = geo_a, geo_b
+        st = HF._store(x)
+        esz = x.element_size()
+        L = nat.lib()
+        need_dx = ctx.needs_input_grad[0]
+        params = (wa, ba, wb, bb, ga, bta, gb, btb, a_c1, a_c2, a_sa, w3, g3, b3, c1, c2, sa)
+        flags = tuple(bool(p is not None and p.requires_grad) for p in params)
+        key = ("dec-b", N, Ci, h, w, Co, geo_a, geo_b, xct, eng, pp, need_dx, flags)
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            (s_x, s_ta, s_tb, s_cat, s_sta, s_stb, s_t3, s_y, s_save, s_dy, s_wka, s_wkb, s_wt3, s_ga, s_bta, s_gb, s_ac1, s_ac2, s_asa,
+             s_g3, s_b3, s_c1, s_c2, s_sa, s_dt3, s_dcat, s_dta, s_dtb, s_dxa, s_dxb, s_dwa, s_dba, s_dwb, s_dbb, s_dga, s_dbta, s_dgb,
+             s_dbtb, s_dac1, s_dac2, s_dasa, s_dw3, s_dg3, s_db3, s_dc1, s_dc2, s_dsa, s_scr3, s_scra, s_scrb, s_ws, s_st,
+             s_side) = ch.slots(53)
+            em = _Emit(ch, eng, s_ws, s_st)
+            ch.call("mgvae_norm_cbam_nhwc_bwd", s_t3, s_g3, s_b3, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt3, None, s_dg3, s_db3,
+                    s_dc1, s_dc2, s_dsa, s_scr3, N, Co, OH, OW, Co, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+            d3 = lambda xc: _desc(N, 2 * Co, OH, OW, Co, OH, OW, (1, 1), (1, 1), (0, 0), xc, Co)
+            if flags[11]:
+                ch.call("mgvae_stream_fork", s_st, s_side)
+                em.bwd_weight(d3(2 * Co), s_cat, s_dt3, s_dw3, s_side)
+            em.bwd_data(d3(2 * Co), s_dt3, s_wt3, None, s_dcat)
+            ch.call("mgvae_instance_norm_nhwc_bwd", s_tb, s_gb, s_stb, s_cat + Co * esz, s_dcat + Co * esz, s_dtb, s_dgb, s_dbtb,
+                    s_scrb, N, Co, OH, OW, 2 * Co, 0, HF.ACT_RELU, 0.01, st, s_st)
+            if pp:
+                ch.call("mgvae_norm_cbam_nhwc_bwd", s_ta, s_ga, s_bta, s_cat, s_dcat, s_ac1, s_ac2, s_asa, s_sta, s_dta, None, s_dga,
+                        s_dbta, s_dac1, s_dac2, s_dasa, s_scra, N, Co, OH, OW, 2 * Co, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+            else:
+                ch.call("mgvae_instance_norm_nhwc_bwd", s_ta, s_ga, s_sta, s_cat, s_dcat, s_dta, s_dga, s_dbta, s_scra, N, Co, OH, OW,
+                        2 * Co, 0, HF.ACT_RELU, 0.01, st, s_st)
+            if flags[0] or flags[1] or flags[2] or flags[3]:
+                ch.call("mgvae_stream_fork", s_st, s_side)
+            # weight gradient of a transposed conv: the roles of the two tensors are swapped (image side = its output)
+            if flags[0]:
+                em.bwd_weight(_desc(N, Co, OH, OW, Ci, h, w, ka, sa_, pa, Co, xct), s_dta, s_x, s_dwa, s_side)
+            if flags[1]:
+                ch.call("mgvae_channel_sum_nhwc_accum", s_dta, N * OH * OW, Co, Co, 0, s_dba, st, s_side)
+            if flags[2]:
+                em.bwd_weight(_desc(N, Co, OH, OW, Ci, h, w, kb, sb_, pb, Co, xct), s_dtb, s_x, s_dwb, s_side)
+            if flags[3]:
+                ch.call("mgvae_channel_sum_nhwc_accum", s_dtb, N * OH * OW, Co, Co, 0, s_dbb, st, s_side)
+            if need_dx:
+                # d/dx of a transposed conv is the forward-conv kernel
+                em.fwd(_desc(N, Co, OH, OW, Ci, h, w, ka, sa_, pa, Co, Ci), s_dta, s_wka, None, s_dxa)
+                em.fwd(_desc(N, Co, OH, OW, Ci, h, w, kb, sb_, pb, Co, Ci), s_dtb, s_wkb, None, s_dxb)
+                ch.call("mgvae_add_inplace_typed", s_dxa, s_dxb, N * Ci * h * w, st, s_st)
+            n3 = int(L.mgvae_norm_cbam_nhwc_scratch_floats(N, Co, OH, OW))
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, n3)
+        ch, wsn, n3 = e
+        dy = _dense_cl(dy, x, Co)
+        wka, _ = _weights(eng, wa)
+        wkb, _ = _weights(eng, wb)
+        _, wt3 = _weights(eng, w3)
+        dt3 = _new(N, Co, OH, OW, x)
+        dcat = _new(N, 2 * Co, OH, OW, x)
+        dta, dtb = _new(N, Co, OH, OW, x), _new(N, Co, OH, OW, x)
+        dxa = _new(N, Ci, h, w, x) if need_dx else None
+        dxb = _new(N, Ci, h, w, x) if need_dx else None
+        scr3 = _f32(n3, x.device)
+        scra = _f32(n3 if pp else 2 * N * Co, x.device)
+        scrb = _f32(2 * N * Co, x.device)
+        ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
+        main, side = _side_for(N, any(flags[:4]) or flags[11], need_dx, (x, cat, dt3, dta, dtb))
+        g = _grad
+        ch.run([x.data_ptr(), ta.data_ptr(), tb.data_ptr(), cat.data_ptr(), sta.data_ptr(), stb.data_ptr(), t3.data_ptr(), y.data_ptr(),
+                save.data_ptr(), dy.data_ptr(), wka.data_ptr(), wkb.data_ptr(), wt3.data_ptr(), ga.data_ptr(), bta.data_ptr(),
+                gb.data_ptr(), _ptr(a_c1), _ptr(a_c2), _ptr(a_sa), g3.data_ptr(), b3.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+                sa.data_ptr(), dt3.data_ptr(), dcat.data_ptr(), dta.data_ptr(), dtb.data_ptr(), _ptr(dxa), _ptr(dxb), _ptr(g(wa)),
+                _ptr(g(ba)), _ptr(g(wb)), _ptr(g(bb)), _ptr(g(ga)), _ptr(g(bta)), _ptr(g(gb)), _ptr(g(btb)), _ptr(g(a_c1)),
+                _ptr(g(a_c2)), _ptr(g(a_sa)), _ptr(g(w3)), _ptr(g(g3)), _ptr(g(b3)), _ptr(g(c1)), _ptr(g(c2)), _ptr(g(sa)),
+                scr3.data_ptr(), scra.data_ptr(), scrb.data_ptr(), _ptr(ws), main, side])
+        return (dxa,) + (None,) * 21
+
+
+def _geo(m):
+    return (tuple(m.kernel_size), tuple(m.stride), tuple(m.padding), tuple(m.output_padding))
+
+
+def deconv_block(x, mod, pp):
+    """``mod``: graph.decoder.DeConvModule (pp False) / DeConvPitchPadding (pp True)"""
+    if pp:
+        na, a = mod.bn2, mod.cbam1          # D5: bn2 on both branches, bn1 never used
+        a_c = (a.channel_attention.conv1.weight, a.channel_attention.conv2.weight, a.spatial_attention.conv.weight)
+        c = mod.cbam2
+    else:
+        na, a_c, c = mod.bn1, (None, None, None), mod.cbam
+    nb = mod.bn2
+    return _DeConvFn.apply(x, mod.deConv1.weight, mod.deConv1.bias, mod.deConv2.weight, mod.deConv2.bias, na.weight, na.bias,
+                           nb.weight, nb.bias, a_c[0], a_c[1], a_c[2], mod.conv.weight, mod.bn3.weight, mod.bn3.bias,
+                           c.channel_attention.conv1.weight, c.channel_attention.conv2.weight, c.spatial_attention.conv.weight,
+                           mod.bn3.eps, bool(pp), _geo(mod.deConv1), _geo(mod.deConv2))

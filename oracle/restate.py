@@ -178,11 +178,10 @@ def deconv_module(sd, p, x):
     return F.relu(o + cbam(sd, p + "cbam.", o))
 
 
-def decoder(sd, p, z, pre_z, phrase_feature, position, train=False, drop_masks=None, taps=None,
-            return_logits=False):
-    """graph/decoder.py:192-222.  ``train`` enables Dropout(0.3); ``drop_masks`` (two
-    pre-scaled {0, 1/0.7} tensors [B,1152]) replaces torch's RNG so the HIP path can be
-    compared on the same mask."""
+def decoder_head(sd, p, z, pre_z, phrase_feature, position, train=False, drop_masks=None):
+    """graph/decoder.py:192-205: embedding gather, the two Linear + ReLU + Dropout(0.3) branches, concat -> [B, 2304, 1, 1].
+    ``drop_masks`` (two pre-scaled {0, 1/0.7} tensors [B,1152]) replaces torch's RNG so the HIP path can be compared on the
+    same mask."""
     def drop(t, i):
         if drop_masks is not None:
             return t * drop_masks[i]
@@ -192,15 +191,28 @@ def decoder(sd, p, z, pre_z, phrase_feature, position, train=False, drop_masks=N
     pf = drop(F.relu(F.linear(pf, sd[p + "phrase_linear.weight"], sd[p + "phrase_linear.bias"])), 0)
     bf = torch.cat((z, pre_z), dim=1)
     bf = drop(F.relu(F.linear(bf, sd[p + "bar_linear.weight"], sd[p + "bar_linear.bias"])), 1)
-    x = torch.cat((bf, pf), dim=1).view(-1, 2304, 1, 1)
+    return torch.cat((bf, pf), dim=1).view(-1, 2304, 1, 1)
+
+
+def decoder_fit1(sd, p, o):
+    """graph/decoder.py:213-215: fit1 -> InstanceNorm -> +CBAM -> ReLU"""
+    o = _island(F.conv2d, o, sd[p + "fit1.weight"])
+    o = instance_norm(sd, p + "bn.", o)
+    return F.relu(o + cbam(sd, p + "cbam.", o))
+
+
+def decoder(sd, p, z, pre_z, phrase_feature, position, train=False, drop_masks=None, taps=None,
+            return_logits=False):
+    """graph/decoder.py:192-222.  ``train`` enables Dropout(0.3); ``drop_masks``: see decoder_head."""
+    x = decoder_head(sd, p, z, pre_z, phrase_feature, position, train, drop_masks)
+    if taps is not None:
+        taps[p + "head"] = x
     pitch = dec_pitch_time(sd, p + "pitch.", x)
     time = dec_time_pitch(sd, p + "time.", x)
     if taps is not None:
         taps[p + "pitch"] = pitch
         taps[p + "time"] = time
-    o = _island(F.conv2d, torch.cat((pitch, time), dim=1), sd[p + "fit1.weight"])
-    o = instance_norm(sd, p + "bn.", o)
-    o = F.relu(o + cbam(sd, p + "cbam.", o))
+    o = decoder_fit1(sd, p, torch.cat((pitch, time), dim=1))
     if taps is not None:
         taps[p + "fit1"] = o
     for i in range(1, len(DEC_LAYERS)):

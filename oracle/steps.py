@@ -259,10 +259,13 @@ def gan2_iteration(gsd, d_sd, f_sd, zb_sd, zp_sd, opts, batch, noise, drop_masks
     return out
 
 
-def sample_phrases(gsd, latents, music_length, songs=1):
-    """maker_bar.py:31-44 (== agent/barGen2.py:317-336) with the Refiner left out (defect D2) and the prior
-    draws passed in: ``latents[idx][bar]`` is the [songs, 1152] latent of bar ``bar`` of phrase ``idx``.  Songs are
-    independent batch entries.  Returns ([songs, music_length * 384, 60] binary roll, list of every bar's sigmoid output)."""
+def sample_phrases(gsd, latents, music_length, songs=1, refiner=False):
+    """maker_bar.py:31-44 (== agent/barGen2.py:317-336) with the prior draws passed in: ``latents[idx][bar]`` is the
+    [songs, 1152] latent of bar ``bar`` of phrase ``idx``.  Songs are independent batch entries.  ``refiner``: apply the
+    D2-fixed Refiner (graph/refiner.py:49-58 through graph/model.py:39-40; ``gsd`` then carries its ``refiner.*`` entries) in
+    eval mode like the rest of the generator (agent/barGen2.py:318) -- BASELINE.json configs[4] as worded; without it the
+    loop is the refiner-less generator of the timed training configs (defect D2).
+    Returns ([songs, music_length * 384, 60] binary roll, list of every bar's output in (0, 1))."""
     dt = latents[0][0].dtype
     pre_phrase = torch.zeros(songs, 1, 384, 60, dtype=dt)
     pre_bar = torch.zeros(songs, 1, 96, 60, dtype=dt)
@@ -274,6 +277,8 @@ def sample_phrases(gsd, latents, music_length, songs=1):
             bars = []
             for b in range(4):
                 gen = R.generator_sample(gsd, latents[idx][b], pre_bar, pre_phrase, pos)
+                if refiner:
+                    gen = R.refiner(gsd, "refiner.", gen, train=False)
                 raw.append(gen)
                 pre_bar = torch.gt(gen, 0.3).to(dt)
                 bars.append(pre_bar.reshape(songs, 96, 60))

@@ -10,7 +10,8 @@ import torch
 
 TOL = 1e-3
 REPORT = []
-TALLY = {"strict": 0, "torch-limited": 0, "flip-noise": 0, "amplified": 0, "flip-tolerant": 0, "l2": 0, "uninformative": 0}
+TALLY = {"strict": 0, "torch-limited": 0, "flip-noise": 0, "amplified": 0, "flip-tolerant": 0, "l2": 0, "segment-strict": 0,
+         "uninformative": 0}
 MARGINS = []      # (margin = error / allowed, name) of every gradient row since the last pop_margins()
 
 
@@ -30,7 +31,7 @@ def check(name, got, want, tol=TOL, atol=0.0):
     assert ok, "%s: abs err %.3e (rel %.3e) > %.1e * %.3e + %.1e" % (name, err, e, tol, scale, atol)
 
 
-def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
+def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None, segment=None):
     """Gradient parity against an fp64 reference ``want``.  Rules, in this order (the first that holds is recorded):
 
       strict          max|got - want| <= tol * max|want| + atol;
@@ -56,6 +57,12 @@ def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
                       in the GAN iteration: all generator rows below decoder.layers.3 sit at one common 0.3 - 0.7 %, run
                       to run, in both layouts, where torch fp32 sits at 0.2 %).  Accepted up to 5 x torch fp32's own L2
                       error and never above 3e-2;
+      segment-strict  (needs ref32 and ``segment``) a row that is chaotic at fp32 resolution in the WHOLE step -- the
+                      reference's own fp32 arithmetic is > 1 % from fp64 on it, because one ReLU / arg-max decision near the top
+                      of a trunk shifts everything below -- but whose SEGMENT of the same backward pass, teacher-forced at
+                      the block boundaries on the fp64 oracle's activations and activation gradients
+                      (tests/segmented.py), passed the strict 2e-3 bound: ``segment`` is that row's rule from the
+                      segmented pass.  The whole-step deviation must still stay within 10 x the fp32 floor;
       flip-tolerant   only without ref32 (single kernels / blocks): at most 2 % of the entries exceed the strict bound
                       and the relative L2 error is <= 5e-2;
       l2              only without ref32: relative L2 error <= l2_ok (caller-supplied).
@@ -83,7 +90,7 @@ def check_grad(name, got, want, tol=TOL, atol=0.0, ref32=None, l2_ok=None):
             l2_32 = max(l2_32, ((r - b).norm() / b.norm().clamp_min(1e-300)).item())
         if e32 > 1e-2:
             if mx <= 10 * e32 * scale:
-                rule = "uninformative"
+                rule = "segment-strict" if segment == "strict" else "uninformative"
             margin = mx / max(10 * e32 * scale, 1e-300)
         elif mx <= 3 * e32 * scale:
             rule, margin = "torch-limited", mx / max(3 * e32 * scale, 1e-300)

@@ -89,3 +89,88 @@ def test_host_helpers_without_a_gpu(built):
     body = re.search(r"typedef struct MgvaeActMask \{(.*?)\} MgvaeActMask;", hdr, re.S).group(1)
     names = re.findall(r"(\w+)\s*[;,]", body)
     assert names == [f[0] for f in nat.ActMask._fields_], (names, nat.ActMask._fields_)
+
+
+def _header_prototypes():
+    hdr = open(os.path.join(ROOT, "include", "mgvae.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mgvae_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", hdr):
+        protos[m.group(2)] = (" ".join(m.group(1).split()), [a.strip() for a in m.group(3).split(",")])
+    return protos
+
+
+def _klass_of_c(arg):
+    """argument class of a C parameter declaration: how it travels in a register / an 8-byte word"""
+    arg = " ".join(arg.split())
+    if arg in ("void", ""):
+        return None
+    if "*" in arg:
+        return "ptr"
+    base = arg.rsplit(" ", 1)[0] if " " in arg else arg
+    base = base.replace("const ", "").strip()
+    return {"int": "i32", "int32_t": "i32", "float": "f32", "double": "f64", "size_t": "u64", "uint64_t": "u64", "long": "i64",
+            "unsigned long long": "u64"}[base]
+
+
+def _klass_of_ctypes(t):
+    if t in (ctypes.c_int, ctypes.c_int32):
+        return "i32"
+    if t is ctypes.c_float:
+        return "f32"
+    if t is ctypes.c_double:
+        return "f64"
+    if t in (ctypes.c_size_t, ctypes.c_uint64):
+        return "u64"
+    if t is ctypes.c_long:
+        return "i64"
+    return "ptr"
+
+
+def test_ctypes_table_matches_the_header_argument_by_argument(built):
+    """hipops/_native.py::SIGNATURES is what the host layer calls through AND what the chain interpreter's dispatch is
+    generated from (tools/gen_chain_dispatch.py): an ``int`` where the header says ``size_t`` would leave the upper half of a
+    register undefined.  Every prototype of include/mgvae.h is parsed and compared class by class."""
+    from hipops import _native as nat
+    protos = _header_prototypes()
+    assert set(protos) == set(nat.SIGNATURES), set(protos) ^ set(nat.SIGNATURES)
+    for name, (ret, args) in protos.items():
+        want = [k for k in (_klass_of_c(a) for a in args) if k is not None]
+        res, argtypes = nat.SIGNATURES[name]
+        got = [_klass_of_ctypes(t) for t in argtypes]
+        assert got == want, (name, got, want)
+        want_res = "ptr" if "*" in ret else {"int": "i32", "size_t": "u64"}[ret.replace("const ", "").strip()]
+        assert _klass_of_ctypes(res) == want_res, (name, ret)
+
+
+def test_chain_dispatch_is_current_and_resolves_every_entry_point(built):
+    """csrc/chain_dispatch.inc (generated, committed) must be what tools/gen_chain_dispatch.py makes from today's table; the
+    built library numbers the entry points the same way; a chain over a cheap host-only entry point runs without a GPU and
+    a failing call reports its index."""
+    import importlib.util
+    import numpy as np
+    from hipops import _native as nat
+    spec = importlib.util.spec_from_file_location("gen_chain_dispatch", os.path.join(ROOT, "tools", "gen_chain_dispatch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(gen.OUT).read() == gen.render(), "stale csrc/chain_dispatch.inc: run python tools/gen_chain_dispatch.py"
+    L = nat.lib()
+    names = [n for n, _ in gen.functions()]
+    assert L.mgvae_chain_fn_count() == len(names)
+    for i, n in enumerate(names):
+        assert L.mgvae_chain_fn_id(n.encode()) == i
+    assert L.mgvae_chain_fn_id(b"mgvae_no_such_entry_point") == -1
+    # two calls of mgvae_set_compute_dtype (host-only state): the second with an invalid code must fail as call 1
+    before = L.mgvae_get_compute_dtype()
+    fid = L.mgvae_chain_fn_id(b"mgvae_set_compute_dtype")
+    calls = (nat.ChainCall * 2)(nat.ChainCall(fid, 1, 0, 0), nat.ChainCall(fid, 1, 1, 0))
+    words = np.array([1, 77], dtype=np.uint64)
+    failed = ctypes.c_int(-5)
+    rc = L.mgvae_chain_run(calls, 2, ctypes.c_void_p(words.ctypes.data), ctypes.byref(failed))
+    assert rc == -1 and failed.value == 1 and L.mgvae_get_compute_dtype() == 1
+    words[1] = before
+    assert L.mgvae_chain_run(calls, 2, ctypes.c_void_p(words.ctypes.data), ctypes.byref(failed)) == 0 and failed.value == -1
+    assert L.mgvae_get_compute_dtype() == before
+    # wrong argument count for the entry point: rejected, nothing called
+    bad = (nat.ChainCall * 1)(nat.ChainCall(fid, 3, 0, 0))
+    assert L.mgvae_chain_run(bad, 1, ctypes.c_void_p(words.ctypes.data), ctypes.byref(failed)) == -1 and failed.value == 0

@@ -139,6 +139,77 @@ def test_sampling_forward_and_loop_at_32_songs(monkeypatch):
     assert parted <= 3, parted
 
 
+def test_sampling_loop_with_refiner_at_32_songs(monkeypatch):
+    """BASELINE.json configs[4] as it is worded -- "phrase_encoder + REFINER long-sequence sampling, batch=32": the
+    generator with the D2-fixed Refiner (graph/refiner.py:49-58 with layer2 taking 2 channels; parity unpinned, the
+    reference raises) in the maker_bar.py:31-44 loop at 32 songs, against the oracle loop that applies restate.refiner
+    after every decoder call.  Teacher-forced single calls first (the refined output is what gets thresholded), then the
+    free-running loop with the same explained-flip rule as the refiner-less test above."""
+    import maker_bar
+    from graph.model import Model
+    songs, length = 32, 2
+    gsd = W.make_state_dict(W.manifest_generator(), 0, "wc")
+    gsd.update(W.make_state_dict(W.manifest_refiner("refiner."), 3, "wc"))
+    # informative BatchNorm statistics for the eval-mode refiner (the manifest's defaults are mean 0 / var 1)
+    gq = torch.Generator().manual_seed(77)
+    for k in list(gsd):
+        if k.startswith("refiner.") and k.endswith("running_mean"):
+            gsd[k] = 0.1 * torch.randn(gsd[k].shape, generator=gq)
+        if k.startswith("refiner.") and k.endswith("running_var"):
+            gsd[k] = 0.5 + torch.rand(gsd[k].shape, generator=gq)
+    gen = Model(use_refiner=True)
+    gen.load_state_dict(gsd)
+    gen = gen.to(dev).eval()
+    g = torch.Generator().manual_seed(2025)
+    lat = [[torch.randn(songs, 1152, generator=g) for _ in range(4)] for _ in range(length)]
+    want_roll, raw = S.sample_phrases(gsd, lat, length, songs, refiner=True)
+    plain_roll, _ = S.sample_phrases(gsd, lat, length, songs, refiner=False)
+    assert not torch.equal(want_roll, plain_roll), "the refiner must matter for this check to mean anything"
+    pre_phrase = torch.zeros(songs, 1, 384, 60); pre_bar = torch.zeros(songs, 1, 96, 60)
+    phrase_idx = [330] + list(range(length - 2, -1, -1))
+    n = 0
+    for idx in range(length):
+        pos = torch.full((songs,), phrase_idx[idx], dtype=torch.long)
+        for b in range(4):
+            with torch.no_grad():
+                out = gen(lat[idx][b].to(dev), pre_bar.to(dev), pre_phrase.to(dev), pos.to(dev), False)
+            check("sampling+refiner forward phrase %d bar %d (32 songs, teacher-forced)" % (idx, b), out, raw[n])
+            pre_bar = (raw[n] > 0.3).float()
+            n += 1
+        pre_phrase = want_roll[:, idx * 384:(idx + 1) * 384].reshape(songs, 1, 384, 60)
+    draws = [t for ph in lat for t in ph]
+    it = iter(draws)
+    monkeypatch.setattr(maker_bar.HF, "randn", lambda shape, sigma=1.0, device="cuda", out=None: next(it).to(device) * sigma)
+    roll = maker_bar.sample(gen, music_length=length, songs=songs, device=dev).cpu()
+    assert tuple(roll.shape) == (songs, length * 384, 60)
+    diff = int((roll != want_roll).sum())
+    REPORT.append("sampling loop WITH refiner, 32 songs x %d phrases: %d of %d cells differ from the oracle loop" % (length, diff, roll.numel()))
+    bars_h = roll.reshape(songs, length * 4, 96, 60)
+    bars_o = want_roll.reshape(songs, length * 4, 96, 60)
+    parted = 0
+    for sng in range(songs):
+        bad = [b for b in range(length * 4) if not torch.equal(bars_h[sng, b], bars_o[sng, b])]
+        if not bad:
+            continue
+        parted += 1
+        b0 = bad[0]
+        cells = bars_h[sng, b0] != bars_o[sng, b0]
+        margin = (raw[b0][sng, 0][cells] - 0.3).abs().max().item()
+        REPORT.append("    song %d parts ways in bar %d: %d cells, farthest oracle output %.2e from the 0.3 threshold" % (sng, b0, int(cells.sum()), margin))
+        assert margin < 1e-4, (sng, b0, margin)
+    assert parted <= 3, parted
+    # the HIP-graph sampler runs the same two programs
+    it2 = iter(draws)
+    monkeypatch.setattr(maker_bar.HF, "randn",
+                        lambda shape, sigma=1.0, device="cuda", out=None: (out.copy_(next(it2).to(device) * sigma) if out is not None else next(it2).to(device) * sigma))
+    gs = maker_bar.GraphSampler(gen, songs=songs, device=dev)
+    it2 = iter(draws)
+    roll_g = gs.sample(length).cpu()
+    same = float((roll_g == roll).float().mean())
+    REPORT.append("GraphSampler with refiner vs eager loop: %.6f of the cells equal" % same)
+    assert same > 0.999
+
+
 # ------------------------------------------------------------------------------------------ agent iterations
 def _agent(tmp_path, monkeypatch, compute_dtype="f32", which="barGen_with_gan"):
     import importlib
@@ -192,18 +263,35 @@ def _masks(b, seed):
     return [(torch.rand(b, 1152, generator=g) >= 0.3).float() / 0.7 for _ in range(2)]
 
 
-def _compare_net(tag, module, hip_grads, oracle_grads, ref32_grads, osd, sd0, lr):
+def _compare_net(tag, module, hip_grads, oracle_grads, ref32_grads, osd, sd0, lr, segment=None):
     """gradients of one network at its step (fp64 oracle is the judge, its fp32 run the reference's own arithmetic),
     then the Adam update the network received"""
     named = dict(module.named_parameters())
     gs = max(g.abs().max().item() for g in oracle_grads.values() if g is not None)
+    names = [n for n, g in oracle_grads.items() if g is not None]
+    if len(names) > 20:
+        # the whole gradient as one vector: direction and size against fp64, next to what the reference's own fp32
+        # arithmetic achieves (plain run and perturbed runs); the HIP step may not be further off than 3 x the worst of them
+        flat = lambda d: torch.cat([d[n].detach().double().cpu().reshape(-1) for n in names])
+        fo, fh = flat(oracle_grads), flat(hip_grads)
+        cos_h = float((fh * fo).sum() / (fh.norm() * fo.norm())); l2_h = float((fh - fo).norm() / fo.norm())
+        runs = len(next(v for v in ref32_grads.values() if v is not None)) if isinstance(next(v for v in ref32_grads.values() if v is not None), list) else 1
+        worst_l2, worst_cos = 0.0, 1.0
+        for r in range(runs):
+            f32 = torch.cat([(ref32_grads[n][r] if runs > 1 or isinstance(ref32_grads[n], list) else ref32_grads[n]).detach().double().reshape(-1) for n in names])
+            worst_l2 = max(worst_l2, float((f32 - fo).norm() / fo.norm())); worst_cos = min(worst_cos, float((f32 * fo).sum() / (f32.norm() * fo.norm())))
+        REPORT.append("%s whole flat gradient vs fp64: hip cos %.8f l2-rel %.3e | torch fp32 (worst of %d runs) cos %.8f l2-rel %.3e" % (
+            tag, cos_h, l2_h, runs, worst_cos, worst_l2))
+        assert l2_h <= max(2e-3, 3 * worst_l2), (tag, l2_h, worst_l2)
+        assert 1 - cos_h <= max(2e-6, 9 * (1 - worst_cos)), (tag, cos_h, worst_cos)
     for n, g in oracle_grads.items():
         if g is None:
             assert hip_grads[n].abs().max().item() == 0, (tag, n)
             continue
         if g.abs().max().item() <= 1e-6 * gs:
             continue
-        check_grad("%s d%s" % (tag, n), hip_grads[n], g, 2 * TOL, atol=1e-6 * gs, ref32=ref32_grads[n])
+        check_grad("%s d%s" % (tag, n), hip_grads[n], g, 2 * TOL, atol=1e-6 * gs, ref32=ref32_grads[n],
+                   segment=(segment or {}).get(n))
         # first Adam step: dw = -lr * g / (|g| + eps) -> compare where the gradient is clear of the noise floor: 1e-3 of the
         # tensor's largest entry, or ten times the gradient error just measured when the row passed through a relaxed rule
         big = g.abs() > max(1e-3, 10 * check_grad.last_rel) * g.abs().max()
@@ -262,6 +350,42 @@ def _oracle(kind, sds, lr, batch, noise, masks, dtype, perturb=None):
     return o, osd
 
 
+def _segmented_wae_generator_step(agent, sds, osd, batch, masks):
+    """the generator step of the WAE iteration (agent/barGen_with_gan.py:426-452), cut at the block boundaries: the HIP
+    generator holds the INITIAL weights (this runs before the agent's own iteration), the latent discriminators are the
+    fp64 oracle's already-updated ones -- exactly what the whole-step generator gradient is taken against.  Every segment
+    strict (tests/segmented.py); returns {parameter name: rule} for the whole-step comparison."""
+    import segmented as SG
+    note, pre_note, pre_phrase, position = batch
+    B = note.shape[0]
+    g64 = {k: v.double() for k, v in sds["generator"].items()}
+    zb = {k: v.detach() for k, v in osd["z_discriminator_bar"].items()}
+    zp = {k: v.detach() for k, v in osd["z_discriminator_phrase"].items()}
+    m64 = [m.double() for m in masks]
+    ones = torch.ones(B, dtype=torch.float64)
+
+    def decode(zz, pf, taps):
+        return R.decoder(g64, "decoder.", zz[:B], zz[B:], pf, position, True, m64, taps)
+
+    def loss_of(gen, zz, pf):
+        loss = R.dloss(R.z_discriminator(zp, "", pf).view(-1), ones)
+        loss = loss + R.dloss(R.z_discriminator(zb, "", zz[:B]).view(-1), ones) + R.dloss(R.z_discriminator(zb, "", zz[B:]).view(-1), ones)
+        return loss + R.bar_loss(gen, note.double(), False)
+
+    enc_in = torch.cat((note, pre_note), 0).double()
+    g64 = {k: v.requires_grad_(True) for k, v in g64.items()}
+    bound, gr, loss = SG.oracle_step(g64, enc_in, pre_phrase.double(), decode, loss_of)
+    bound["__enc_in"], bound["__phrase_in"] = enc_in, pre_phrase.double()
+    rep = SG.segmented_generator_check(agent.generator, agent.opt_generator, sds["generator"], bound, gr, position, m64, B=B)
+    rules = {k: v for k, v in rep.items() if ":dx" not in k}
+    bad = sorted(k for k, v in rules.items() if v != "strict")
+    REPORT.append("WAE generator step, segmented: %d parameter rows + %d boundary gradients; not strict: %s" % (
+        len(rules), len(rep) - len(rules), bad))
+    assert len(rules) >= 180, len(rules)
+    assert len(bad) <= 0.05 * len(rules), bad           # (an in-segment arg-max tie may still fall the other way)
+    return rules
+
+
 def test_train_wae_iteration_against_oracle(tmp_path, monkeypatch):
     agent, sds, grads = _agent(tmp_path, monkeypatch)
     lr = agent.config.learning_rate
@@ -275,9 +399,10 @@ def test_train_wae_iteration_against_oracle(tmp_path, monkeypatch):
     agent.epoch = 1
     from metrics import AverageMeter
     meters = {k: AverageMeter() for k in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+    o, osd = _oracle("wae", sds, lr, batch, noise, masks, torch.float64)
+    seg = _segmented_wae_generator_step(agent, sds, osd, batch, masks)
     out = agent.train_wae(*(t.to(dev) for t in batch), meters, 0)          # (epoch + curr_it) % 2 == 1: both halves run
     torch.cuda.synchronize()
-    o, osd = _oracle("wae", sds, lr, batch, noise, masks, torch.float64)
     o32, _ = _oracle("wae", sds, lr, batch, noise, masks, torch.float32)
     o32 = _with_perturbed(o32, lambda seed: _oracle("wae", sds, lr, batch, noise, masks, torch.float32, perturb=seed)[0])
     check("train_wae phraseZ discriminator loss", meters["z_phrase"].val, o["phrase_loss"])
@@ -289,7 +414,9 @@ def test_train_wae_iteration_against_oracle(tmp_path, monkeypatch):
     _compare_net("train_wae z_bar", agent.z_discriminator_bar, grads["z_discriminator_bar"], o["grad_z_bar"],
                  o32["grad_z_bar"], osd["z_discriminator_bar"], sds["z_discriminator_bar"], lr)
     _compare_net("train_wae generator", agent.generator, grads["generator"], o["grad_generator"], o32["grad_generator"], osd["generator"],
-                 sds["generator"], lr)
+                 sds["generator"], lr, segment=seg)
+    from parity_util import TALLY
+    REPORT.append("train_wae tally after the generator rows: %s" % dict(TALLY))
     pop_margins("train_wae iteration vs fp64 oracle", 10)
     assert set(grads) == {"generator", "z_discriminator_bar", "z_discriminator_phrase"}      # nothing else stepped
     assert agent.opt_discriminator.step_count == 0 and agent.opt_generator.step_count == 1

@@ -243,6 +243,96 @@ def test_channels_last_blocks_against_oracle(mode):
             assert p.grad.data_ptr() >= opt.grad.data_ptr()          # accumulated straight into the flat gradient
 
 
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_chained_blocks_equal_the_per_op_path(storage):
+    """hipops/blocks.py (one autograd node + one mgvae_chain_run per block and direction) against the per-op autograd
+    functions it replaces, on the same inputs: the chain issues the SAME entry points in the same order, so the forward is
+    bit-identical and the gradients agree to the weight gradients' atomic summation order -- for every chained block type,
+    in fp32 (x3 engine) and bf16 storage, with the gradient flowing into the input (need_dx) and not."""
+    import graph.encodingBlock as EB
+    import graph.decoder as DD
+    from graph.cbam import CBAM
+    from graph.layers import Conv2d, InstanceNorm2d
+    from hipops import FlatParams
+    from hipops import blocks as HB
+    from hipops import functional as HF
+
+    class Fit(torch.nn.Module):                 # the decoder's fit1 stage: 1x1 conv -> InstanceNorm -> +CBAM -> ReLU
+        def __init__(self):
+            super().__init__()
+            self.fit1 = Conv2d(256, 128, 1, stride=1, bias=False, channels_last=True)
+            self.bn = InstanceNorm2d(128)
+            self.cbam = CBAM(128)
+
+        def forward(self, o):
+            if HB.usable(o):
+                return HB.conv_norm_cbam_block(o, self.fit1, self.bn, self.cbam)
+            return self.cbam.fused_norm(self.fit1(o), self.bn, 1, act=HF.ACT_RELU, channels_last=True)
+
+    cases = [("residual64", lambda: EB.ResidualModule(64, True), (3, 64, 24, 30)),
+             ("residual512", lambda: EB.ResidualModule(512, True), (4, 512, 6, 4)),
+             ("pooling64", lambda: EB.PoolingModule(64, 128, True), (3, 64, 48, 30)),
+             ("pooling odd", lambda: EB.PoolingModule(128, 256, True), (2, 128, 24, 15)),
+             ("fit", Fit, (3, 256, 6, 3)),
+             ("deconv_pp", lambda: DD.DeConvPitchPadding(512, 256, True), (3, 512, 12, 7)),
+             ("deconv", lambda: DD.DeConvModule(128, 64, True), (2, 128, 24, 30))]
+    HF.set_compute_dtype(storage)
+    fork_min = HF.FORK_MIN_BATCH
+    HF.FORK_MIN_BATCH = 1           # fork the weight gradients onto the side stream even at these small batches
+    try:
+        for tag, mk, shape in cases:
+            torch.manual_seed(11)
+            mod = mk().to(dev)
+            with torch.no_grad():
+                for prm in mod.parameters():
+                    if prm.dim() > 1:
+                        prm.mul_(0.05).add_(0.01 * torch.randn_like(prm))      # tame the N(-1,1) init: informative outputs
+            opt = FlatParams(list(mod.parameters()))
+            x = torch.randn(shape).relu_()
+            dy = None
+            res = {}
+            for need_dx in (True, False):
+                for chained in (False, True):
+                    HB.ENABLED = chained
+                    opt.zero_grad()
+                    xd = x.to(dev).requires_grad_(need_dx)
+                    xi = HF.to_channels_last(xd) if need_dx else HF.to_channels_last(xd).detach()
+                    y = mod(xi)
+                    if dy is None:
+                        dy = torch.randn(y.shape, device=dev)
+                    y.backward(dy.to(y.dtype) if y.dtype != dy.dtype else dy)
+                    torch.cuda.synchronize()
+                    res[(need_dx, chained)] = (y.detach().float().clone(), xd.grad.clone() if need_dx else None, opt.grad.clone())
+                    fn = type(y.grad_fn).__name__
+                    assert ("Residual" in fn or "ConvNormCbam" in fn or "DeConv" in fn) == chained, (tag, chained, fn)
+                (y0, dx0, g0), (y1, dx1, g1) = res[(need_dx, False)], res[(need_dx, True)]
+                assert torch.equal(y0, y1), "%s [%s]: chained forward differs from the per-op forward" % (tag, storage)
+                gs = float(g0.abs().max())
+                assert gs > 0
+                tol = 1e-5 if storage == "f32" else 2e-2      # bf16: dx of a two-consumer input is summed in bf16 (one more rounding)
+                # bf16 storage: the InstanceNorm backward's atomically summed statistics move the last bit of a few bf16-stored
+                # gradient values from run to run, and an analytically ZERO weight-like gradient (the bias of a conv in front
+                # of an InstanceNorm) is the sum of exactly that noise: measured 3e-4 of the largest gradient entry
+                gtol = 1e-5 if storage == "f32" else 2e-3
+                assert float((g0 - g1).abs().max()) <= gtol * gs, (tag, storage, need_dx, float((g0 - g1).abs().max()) / gs)
+                if need_dx:
+                    assert float((dx0 - dx1).abs().max()) <= tol * float(dx0.abs().max()), (tag, storage, float((dx0 - dx1).abs().max()))
+            # a frozen block (the generator inside a discriminator step) still back-propagates to its input
+            HB.ENABLED = True
+            for prm in mod.parameters():
+                prm.requires_grad = False
+            opt.zero_grad()
+            xd = x.to(dev).requires_grad_(True)
+            mod(HF.to_channels_last(xd)).backward(dy.to(HF.island_dtype()))
+            torch.cuda.synchronize()
+            assert float(opt.grad.abs().max()) == 0.0
+            assert float((xd.grad - res[(True, True)][1]).abs().max()) <= 1e-5 * float(xd.grad.abs().max()) + (2e-2 * float(xd.grad.abs().max()) if storage == "bf16" else 0)
+    finally:
+        HB.ENABLED = True
+        HF.FORK_MIN_BATCH = fork_min
+        HF.set_compute_dtype("f32")
+
+
 BF16_BLOCKS = ["residual64", "pooling64", "residual128", "residual512", "pooling512", "deconv_pp1024", "deconv_pp512", "deconv256", "deconv128"]
 
 
