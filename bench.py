@@ -13,9 +13,12 @@ The Refiner is excluded (it raises in the reference: defect D2).  Weak scaling: 
 batch stays 64 as N grows.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel family (implicit-GEMM convs on the fp32 MFMA pipe):
-                  algorithmic FLOPs / HIP-event time measured live, per kernel variant,
-                  against the 157.3 TFLOP/s dense fp32 matrix peak of MI355X;
+  roofline     -- the dominant kernel family (the channels-last convs): algorithmic FLOPs / HIP-event time
+                  measured live, per kernel variant, each variant against the peak of the matrix
+                  instruction it runs on -- 2500 / 6 = 416.7 TFLOP/s fp32-equivalent for the default fp32
+                  engine (six dense-bf16 MFMAs per fp32 product, csrc/conv_nhwc_x3.inc), 2500 for bf16
+                  storage, 157.3 for the kernels on v_mfma_f32_32x32x2_f32; ``traffic`` / ``mfma_busy_pmc``
+                  come from a committed PMC summary of THESE kernel sources, else null;
   cpu_baseline -- the CPU oracle (a restatement pinned bit-for-bit to the reference import)
                   running the same step on this host's cores (rank 0, N=1 only): batch 64 on all cores
                   (the GPU's workload), batch 4 on all cores and on 8 threads beside it.
@@ -114,21 +117,44 @@ def cpu_baseline():
     return main
 
 
+def kernel_source_tag():
+    """sha256 over the kernel sources (csrc/*.hip, *.inc, *.h and include/mgvae.h): identifies WHICH kernels a PMC summary
+    was taken on (tools/pmc_summary.py stamps it into the summary; pmc_record only quotes a summary whose tag is this one)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.inc")) +
+                   glob.glob(os.path.join(PKG, "csrc", "*.h"))) + [os.path.join(ROOT, "include", "mgvae.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_record(kernel):
     """HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) and the
-    MFMA-busy share of ``kernel`` from the newest committed PMC summary (profiles/rN?_pmc_summary.json, written by
-    tools/pmc_collect.sh + tools/pmc_summary.py: counters cannot be read from inside this process)."""
+    MFMA-busy share of ``kernel`` from a committed PMC summary (profiles/rN?_pmc_summary.json, written by
+    tools/pmc_collect.sh + tools/pmc_summary.py: counters cannot be read from inside this process) -- but ONLY from a summary
+    that was collected on these kernel sources (its ``_kernel_source_tag`` equals kernel_source_tag()).  Counters of another
+    build say nothing about this run: the fields are then null and ``traffic_source`` says which summary was passed over."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
         return None
-    try:
-        rec = json.load(open(files[-1])).get(kernel)
-    except (OSError, ValueError):
-        return None
-    if rec:
-        rec = dict(rec, source="profiles/" + os.path.basename(files[-1]))
-    return rec
+    tag = kernel_source_tag()
+    stale = None
+    for f in reversed(files):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if doc.get("_kernel_source_tag") != tag:
+            stale = stale or os.path.basename(f)
+            continue
+        rec = doc.get(kernel)
+        if rec:
+            return dict(rec, source="profiles/" + os.path.basename(f))
+    return {"source": "none for this build (newest summary, profiles/%s, is of other kernel sources)" % stale} if stale else None
 
 
 def main():

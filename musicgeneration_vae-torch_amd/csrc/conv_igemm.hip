@@ -1411,7 +1411,7 @@ static void choice_load_locked() {
         for (int i = 0; i < 14; ++i) n += fscanf(fp, "%d", &k.v[i]);
         n += fscanf(fp, "%d %d", &c.tile, &c.split);
         if (n != 16) break;
-        if (c.tile >= 0 && c.tile < 12 && c.split >= 1 && c.split <= 4096) g_choice[k] = c;     // tile / 4: loop form of the x3 family
+        if (c.tile >= 0 && c.tile < 16 && c.split >= 1 && c.split <= 4096) g_choice[k] = c;     // tile / 4: loop form of the x3 family (3 = halo)
     }
     fclose(fp);
 }
@@ -1873,7 +1873,7 @@ extern "C" int mgvae_prof_detail(const char* path) {
 
 extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    constexpr int SLOTS = 12;          // variant ids per kind (the x3 family has 3 loop forms x 4 tile shapes)
+    constexpr int SLOTS = 16;          // variant ids per kind (the x3 family: 3 loop forms + the halo form, x 4 tile shapes)
     MgvaeProfRec recs[MGVAE_PROF_KINDS * SLOTS];
     for (int k = 0; k < MGVAE_PROF_KINDS; ++k)
         for (int t = 0; t < SLOTS; ++t) recs[k * SLOTS + t] = MgvaeProfRec{k, t, 0, 0.0, 0.0};
@@ -1902,12 +1902,13 @@ extern "C" int mgvae_prof_collect(MgvaeProfRec* out, int cap) {
 extern "C" const char* mgvae_kernel_name(int kind, int tile) {
     static const char* tiles[5] = {"2, 2", "1, 2", "2, 1", "1, 1", "4, 2"};
     static char buf[5][7][48];
-    static char nbuf[9][12][48];
-    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 9 && tile >= 0 && tile < (kind >= MGVAE_PROF_NHWC_X3_FWD ? 12 : 4)) {
+    static char nbuf[9][16][48];
+    if (kind >= MGVAE_PROF_NHWC_FWD && kind < MGVAE_PROF_NHWC_FWD + 9 && tile >= 0 && tile < (kind >= MGVAE_PROF_NHWC_X3_FWD ? 16 : 4)) {
         const int m = kind - MGVAE_PROF_NHWC_FWD;
-        static const char* fam[5] = {"nhwc_igemm_kernel<%d, %s>", "nhwc_igemm_bf16_kernel<%d, %s>", "nhwc_igemm_x3_kernel<%d, %s>",
-                                     "nhwc_igemm_x3s_kernel<%d, %s>", "nhwc_igemm_x3w_kernel<%d, %s>"};
-        snprintf(nbuf[m][tile], 48, fam[m / 3 + tile / 4], m % 3, tiles[tile & 3]);
+        static const char* fam[6] = {"nhwc_igemm_kernel<%d, %s>", "nhwc_igemm_bf16_kernel<%d, %s>", "nhwc_igemm_x3_kernel<%d, %s>",
+                                     "nhwc_igemm_x3s_kernel<%d, %s>", "nhwc_igemm_x3w_kernel<%d, %s>", "nhwc_halo_x3_kernel<%d, %s>"};
+        if (tile >= 12) snprintf(nbuf[m][tile], 48, fam[5], m % 3, tile == 15 ? "4, 1" : ((tile & 2) ? "2, 1" : "2, 2"));   // halo form: <MODE, TI, TJ>
+        else snprintf(nbuf[m][tile], 48, fam[m / 3 + tile / 4], m % 3, tiles[tile & 3]);
         return nbuf[m][tile];
     }
     if (kind == MGVAE_PROF_ADAM) return "adam_kernel";

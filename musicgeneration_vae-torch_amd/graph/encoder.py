@@ -4,6 +4,7 @@ import os
 import torch
 from torch import nn
 
+from hipops import blocks as HB
 from hipops import functional as HF
 from graph.encodingBlock import PitchTimeModule, PoolingModule, ResidualModule, TimePitchModule
 from graph.layers import Linear
@@ -47,9 +48,12 @@ class _ConvTrunk(nn.Module):
 
     def features(self, x):
         """the conv trunk up to the pooled [n, 1024] features (everything but the final Linear)"""
-        o = self.stem_cat(x)
-        if self.channels_last:
-            o = HF.to_channels_last(o)
+        if self.channels_last and HB.entry_usable(x):
+            o = HB.trunk_entry(x, self)            # both stems + the layout change: one node, one launch chain
+        else:
+            o = self.stem_cat(x)
+            if self.channels_last:
+                o = HF.to_channels_last(o)
         # when the gradient of this tensor exists, every parameter gradient of ``layers`` and ``linear`` is enqueued:
         # the data-parallel step hooks it to start that range's all-reduce early (hipops/train.py)
         self.trunk_input = o if o.requires_grad else None

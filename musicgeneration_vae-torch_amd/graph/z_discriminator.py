@@ -4,6 +4,7 @@ is one implicit-GEMM HIP launch.  ``net`` keeps the reference's Sequential indic
 (0,2,4,6,8) so state_dict keys match."""
 from torch import nn
 
+from hipops import blocks as HB
 from hipops import functional as HF
 from graph.layers import Linear
 from graph.weights_initializer import weights_init
@@ -28,6 +29,8 @@ class _ZDisc(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x):
+        if HB.mlp_usable(x):         # the five Linears as one autograd node and one launch chain per direction
+            return HB.mlp(x, [(self.net[i].weight, self.net[i].bias, HF.ACT_RELU if i < 8 else HF.ACT_SIGMOID) for i in (0, 2, 4, 6, 8)])
         for i in (0, 2, 4, 6):
             x = self.net[i](x, act=HF.ACT_RELU)
         return self.net[8](x, act=HF.ACT_SIGMOID)

@@ -486,3 +486,243 @@ def deconv_block(x, mod, pp):
                            nb.weight, nb.bias, a_c[0], a_c[1], a_c[2], mod.conv.weight, mod.bn3.weight, mod.bn3.bias,
                            c.channel_attention.conv1.weight, c.channel_attention.conv2.weight, c.spatial_attention.conv.weight,
                            mod.bn3.eps, bool(pp), _geo(mod.deConv1), _geo(mod.deConv2))
+
+
+# ======================================================================================= NCHW ends: MLPs and stems
+def _pitch2d(x):
+    """row pitch (floats) of a 2-D fp32 tensor [B, K] that is dense or a column slice; else a dense copy"""
+    if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    return x, (x.stride(0) if x.shape[0] > 1 else x.shape[1])
+
+
+class _MlpFn(torch.autograd.Function):
+    """a stack of nn.Linear (+ bias) (+ ReLU / sigmoid): the latent discriminators (graph/z_discriminator.py:28-29,53-54)
+    and the feature discriminator (graph/bar_discriminator_with_feature.py:17-25).  Every Linear is the 1x1 implicit GEMM /
+    skinny GEMM of mgvae_conv2d_fwd with the activation in its epilogue, as in hipops.functional.linear."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *wb):
+        HF._need_cuda(x, "mlp")
+        x, xct = _pitch2d(x)
+        B, K = x.shape
+        nl = len(acts)
+        ws, bs = wb[:nl], wb[nl:]
+        dims = [K] + [w.shape[0] for w in ws]
+        key = ("mlp-f", B, xct, tuple(dims), acts, tuple(b is not None for b in bs))
+        ch = _chains.get(key)
+        if ch is None:
+            ch = Chain()
+            s_in = ch.slot()
+            s_w, s_b, s_h = ch.slots(nl), ch.slots(nl), ch.slots(nl)
+            s_st = ch.slot()
+            cur, ct = s_in, xct
+            for i in range(nl):
+                d = _desc(B, dims[i], 1, 1, dims[i + 1], 1, 1, (1, 1), (1, 1), (0, 0), ct, dims[i + 1], acts[i], 0.01)
+                ch.call("mgvae_conv2d_fwd", ch.struct(d), cur, s_w[i], s_b[i] if bs[i] is not None else None, s_h[i], s_st)
+                cur, ct = s_h[i], dims[i + 1]
+            ch = _chains[key] = ch.finalize()
+        hs = [torch.empty((B, dims[i + 1]), device=x.device, dtype=torch.float32) for i in range(nl)]
+        ch.run([x.data_ptr()] + [w.data_ptr() for w in ws] + [_ptr(b) for b in bs] + [h.data_ptr() for h in hs] + [_main()])
+        ctx.save_for_backward(x, *ws, *bs, *hs)
+        ctx.cfg = (acts, xct, nl)
+        return hs[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        acts, xct, nl = ctx.cfg
+        sv = ctx.saved_tensors
+        x, ws, bs, hs = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:]
+        B, K = x.shape
+        dims = [K] + [w.shape[0] for w in ws]
+        need_dx = ctx.needs_input_grad[0]
+        wflags = tuple(bool(w.requires_grad) for w in ws)
+        bflags = tuple(bool(b is not None and b.requires_grad) for b in bs)
+        key = ("mlp-b", B, xct, tuple(dims), acts, need_dx, wflags, bflags)
+        ch = _chains.get(key)
+        if ch is None:
+            ch = Chain()
+            s_in, s_dy, s_dx = ch.slots(3)
+            s_w, s_h, s_dpre, s_dh, s_dw, s_db = ch.slots(nl), ch.slots(nl), ch.slots(nl), ch.slots(nl), ch.slots(nl), ch.slots(nl)
+            s_st, s_side = ch.slots(2)
+            g = s_dy                                    # gradient of layer i's (activated) output
+            for i in range(nl - 1, -1, -1):
+                ci, co = dims[i], dims[i + 1]
+                if acts[i] != HF.ACT_NONE:
+                    ch.call("mgvae_act_bwd", s_h[i], g, s_dpre[i], B, co, 1, co, 0, co, 0, co, 0, acts[i], 0.01, s_st)
+                    g = s_dpre[i]
+                src, sct = (s_in, xct) if i == 0 else (s_h[i - 1], ci)
+                if wflags[i] or bflags[i]:
+                    ch.call("mgvae_stream_fork", s_st, s_side)
+                if wflags[i]:
+                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(B, ci, 1, 1, co, 1, 1, (1, 1), (1, 1), (0, 0), sct, co)), src, g,
+                            s_dw[i], s_side)
+                if bflags[i]:
+                    ch.call("mgvae_channel_sum_accum", g, B, co, 1, co, 0, s_db[i], s_side)
+                if i > 0 or need_dx:
+                    dst = s_dx if i == 0 else s_dh[i - 1]
+                    ch.call("mgvae_conv2d_bwd_data", ch.struct(_desc(B, ci, 1, 1, co, 1, 1, (1, 1), (1, 1), (0, 0), ci, co)), g, s_w[i],
+                            None, dst, s_st)
+                    g = dst
+            ch = _chains[key] = ch.finalize()
+        dy = dy.contiguous()
+        dev = x.device
+        dpre = [torch.empty((B, dims[i + 1]), device=dev, dtype=torch.float32) if acts[i] != HF.ACT_NONE else None for i in range(nl)]
+        dh = [torch.empty((B, dims[i + 1]), device=dev, dtype=torch.float32) for i in range(nl - 1)] + [None]
+        dx = torch.empty((B, K), device=dev, dtype=torch.float32) if need_dx else None
+        main, side = _side_for(B, any(wflags) or any(bflags), need_dx, (x,) + tuple(hs) + tuple(t for t in dpre if t is not None) + (dy,))
+        ch.run([x.data_ptr(), dy.data_ptr(), _ptr(dx)] + [w.data_ptr() for w in ws] + [h.data_ptr() for h in hs] + [_ptr(t) for t in dpre]
+               + [_ptr(t) for t in dh] + [_ptr(_grad(w)) for w in ws] + [_ptr(_grad(b)) for b in bs] + [main, side])
+        return (dx, None) + (None,) * (2 * nl)
+
+
+def mlp(x, layers):
+    """``layers``: [(weight [Cout, Cin], bias or None, activation)]; x [B, Cin] -> [B, Cout of the last layer]"""
+    ws = tuple(l[0] for l in layers)
+    bs = tuple(l[1] for l in layers)
+    return _MlpFn.apply(x, tuple(int(l[2]) for l in layers), *ws, *bs)
+
+
+def mlp_usable(x):
+    return ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and HF.get_nchw_operand_dtype() == "f32" and not HF.USE_DIRECT
+
+
+class _TrunkEntryFn(torch.autograd.Function):
+    """Both stems of an encoder trunk (graph/encodingBlock.py:25-36,56-67: thin conv -> LeakyReLU -> thin conv -> InstanceNorm ->
+    +CBAM -> LeakyReLU, each writing its half of the concat of graph/encoder.py:27-29) and the layout change into the
+    channels-last island, as one node: [N,1,H,W] fp32 -> channels-last [N,64,H/2,W/2] of the island's storage type."""
+
+    @staticmethod
+    def forward(ctx, x, eps, geo, dtype, *prm):
+        HF._need_cuda(x, "trunk entry")
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        OH, OW = H // 2, W // 2
+        P, NC = OH * OW, N * 32
+        st = HF.STORE_BF16 if dtype == torch.bfloat16 else HF.STORE_F32
+        key = ("entry-f", N, H, W, geo, st, float(eps))
+        e = _chains.get(key)
+        L = nat.lib()
+        if e is None:
+            ch = Chain()
+            s_x, s_cat, s_ycl, s_st = ch.slots(4)
+            stems = []
+            for si in range(2):
+                (k1, s1, p1), (k2, s2, p2) = geo[si]
+                H1, W1 = (H + 2 * p1[0] - k1[0]) // s1[0] + 1, (W + 2 * p1[1] - k1[1]) // s1[1] + 1
+                if ((H1 + 2 * p2[0] - k2[0]) // s2[0] + 1, (W1 + 2 * p2[1] - k2[1]) // s2[1] + 1) != (OH, OW):
+                    raise RuntimeError("trunk entry: a stem does not halve the map")
+                s_w1, s_w2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_u, s_stats, s_save = ch.slots(12)
+                stems.append((H1, W1))
+                ch.call("mgvae_conv2d_fwd", ch.struct(_desc(N, 1, H, W, 32, H1, W1, k1, s1, p1, 1, 32, HF.ACT_LEAKY, 0.01)), s_x, s_w1, None,
+                        s_t1, s_st)
+                ch.call("mgvae_conv2d_fwd", ch.struct(_desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)), s_t1, s_w2, None, s_t2, s_st)
+                ch.call("mgvae_instance_norm_fwd", s_t2, s_g, s_b, s_u, s_stats, N, 32, P, 32, 0, eps, HF.ACT_NONE, 0.0, s_save + 4 * NC,
+                        s_save + 8 * NC, s_save + 12 * NC, s_st)
+                ch.call("mgvae_cbam_fwd", s_u, None, s_c1, s_c2, s_sa, s_cat + 4 * si * 32 * P, s_save, N, 32, OH, OW, 64, 0, 1, HF.ACT_LEAKY,
+                        0.01, 3 | 4, s_st)
+            ch.call("mgvae_layout_nchw_to_nhwc", s_cat, s_ycl, N, 64, P, 64, 0, 64, 0, st, s_st)
+            e = _chains[key] = (ch.finalize(), stems, int(L.mgvae_cbam_save_floats(N, 32, OH, OW)))
+        ch, stems, nsave = e
+        dev = x.device
+        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        cat = f(N, 64, OH, OW)
+        ycl = HF.new_channels_last(N, 64, OH, OW, dev, dtype)
+        addr = [x.data_ptr(), cat.data_ptr(), ycl.data_ptr(), _main()]
+        keep = []
+        for si in range(2):
+            w1, w2, g, b, c1, c2, sa = prm[7 * si:7 * si + 7]
+            H1, W1 = stems[si]
+            t1, t2, u, stats, save = f(N, 32, H1, W1), f(N, 32, OH, OW), f(N, 32, OH, OW), f(2 * NC), f(nsave)
+            keep += [t1, t2, u, stats, save]
+            addr += [w1.data_ptr(), w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(),
+                     t2.data_ptr(), u.data_ptr(), stats.data_ptr(), save.data_ptr()]
+        ch.run(addr)              # slot order: the four shared slots first, then 12 per stem
+        ctx.save_for_backward(x, cat, *prm, *keep)
+        ctx.cfg = (float(eps), geo, st, stems, dtype)
+        return ycl
+
+    @staticmethod
+    def backward(ctx, dy):
+        eps, geo, st, stems, dtype = ctx.cfg
+        sv = ctx.saved_tensors
+        x, cat, prm, keep = sv[0], sv[1], sv[2:16], sv[16:]
+        N, _, H, W = x.shape
+        OH, OW = H // 2, W // 2
+        P, NC, NP = OH * OW, N * 32, N * OH * OW
+        flags = tuple(bool(p.requires_grad) for p in prm)
+        tw = bool(HF.USE_TRANSPOSED_W)
+        key = ("entry-b", N, H, W, geo, st, flags, tw)
+        e = _chains.get(key)
+        L = nat.lib()
+        if e is None:
+            ch = Chain()
+            s_x, s_cat, s_dy, s_dcat, s_st, s_side = ch.slots(6)
+            ch.call("mgvae_layout_nhwc_to_nchw", s_dy, s_dcat, N, 64, P, 64, 0, 64, 0, st, s_st)
+            for si in range(2):
+                (k1, s1, p1), (k2, s2, p2) = geo[si]
+                H1, W1 = stems[si]
+                fl = flags[7 * si:7 * si + 7]
+                (s_w2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_u, s_stats, s_save, s_du, s_dt2, s_dt1, s_dt1a, s_wt, s_scr, s_dw1, s_dw2, s_dg,
+                 s_db, s_dc1, s_dc2, s_dsa) = ch.slots(24)
+                off = 4 * si * 32 * P
+                ch.call("mgvae_cbam_bwd", s_u, s_cat + off, s_dcat + off, s_c1, s_c2, s_sa, s_save, s_du, None, s_dc1, s_dc2, s_dsa, s_scr,
+                        N, 32, OH, OW, 64, 0, 1, HF.ACT_LEAKY, 0.01, 3 | 4, s_st)
+                ch.call("mgvae_instance_norm_bwd", s_t2, s_g, s_b, s_stats, s_du, s_dt2, s_dg, s_db, N, 32, P, 32, 0, HF.ACT_NONE, 0.0,
+                        s_scr + 4 * (3 * NP + NC), s_scr + 4 * (3 * NP + 2 * NC), s_save + 12 * NC, s_st)
+                if fl[1]:
+                    ch.call("mgvae_stream_fork", s_st, s_side)
+                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)), s_t1, s_dt2, s_dw2, s_side)
+                d2 = _desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)
+                if tw and k2[0] * k2[1] > 1:
+                    ch.call("mgvae_weight_transpose", s_w2, s_wt, 32, 32, k2[0] * k2[1], s_st)
+                    ch.call("mgvae_conv2d_bwd_data_tw", ch.struct(d2), s_dt2, s_wt, None, s_dt1, s_st)
+                else:
+                    ch.call("mgvae_conv2d_bwd_data", ch.struct(d2), s_dt2, s_w2, None, s_dt1, s_st)
+                if fl[0]:
+                    ch.call("mgvae_act_bwd", s_t1, s_dt1, s_dt1a, N, 32, H1 * W1, 32, 0, 32, 0, 32, 0, HF.ACT_LEAKY, 0.01, s_st)
+                    ch.call("mgvae_stream_fork", s_st, s_side)
+                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(N, 1, H, W, 32, H1, W1, k1, s1, p1, 1, 32)), s_x, s_dt1a, s_dw1, s_side)
+            e = _chains[key] = (ch.finalize(), int(L.mgvae_cbam_bwd_scratch_floats(N, 32, OH, OW)))
+        ch, nscr = e
+        dev = x.device
+        if dy.dtype != dtype:
+            dy = dy.to(dtype)
+        if HF.cl_pitch(dy) != 64:
+            dy = dy.contiguous(memory_format=HF.CL)
+        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        dcat = f(N, 64, OH, OW)
+        touched = [x, dcat]
+        main_side = None
+        addr_stems = []
+        tmp = []
+        for si in range(2):
+            w1, w2, g, b, c1, c2, sa = prm[7 * si:7 * si + 7]
+            t1, t2, u, stats, save = keep[5 * si:5 * si + 5]
+            H1, W1 = stems[si]
+            du, dt2, dt1, dt1a, wt, scr = f(N, 32, OH, OW), f(N, 32, OH, OW), f(N, 32, H1, W1), f(N, 32, H1, W1), f(w2.numel()), f(nscr)
+            tmp += [du, dt2, dt1, dt1a, wt, scr]
+            touched += [t1, dt2, dt1a]
+            addr_stems += [w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(), t2.data_ptr(),
+                           u.data_ptr(), stats.data_ptr(), save.data_ptr(), du.data_ptr(), dt2.data_ptr(), dt1.data_ptr(), dt1a.data_ptr(),
+                           wt.data_ptr(), scr.data_ptr(), _ptr(_grad(w1)), _ptr(_grad(w2)), _ptr(_grad(g)), _ptr(_grad(b)), _ptr(_grad(c1)),
+                           _ptr(_grad(c2)), _ptr(_grad(sa))]
+        main, side = _side_for(N, any(flags), True, touched)
+        ch.run([x.data_ptr(), cat.data_ptr(), dy.data_ptr(), dcat.data_ptr(), main, side] + addr_stems)
+        return (None,) * (4 + 14)
+
+
+def trunk_entry(x, trunk):
+    """``trunk``: graph.encoder._ConvTrunk; its two stems in concat order (pitch_time -> channels 0..31, time_pitch -> 32..63)"""
+    prm, geo = [], []
+    for stem in (trunk.pitch_time, trunk.time_pitch):
+        a, b = getattr(stem, stem.first), getattr(stem, stem.second)
+        ca, sa = stem.cbam.channel_attention, stem.cbam.spatial_attention
+        prm += [a.weight, b.weight, stem.bn.weight, stem.bn.bias, ca.conv1.weight, ca.conv2.weight, sa.conv.weight]
+        geo.append(((tuple(a.kernel_size), tuple(a.stride), tuple(a.padding)), (tuple(b.kernel_size), tuple(b.stride), tuple(b.padding))))
+    return _TrunkEntryFn.apply(x, trunk.pitch_time.bn.eps, tuple(geo), HF.island_dtype(), *prm)
+
+
+def entry_usable(x):
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1 and not x.requires_grad
+            and HF.get_nchw_operand_dtype() == "f32" and not HF.USE_DIRECT)

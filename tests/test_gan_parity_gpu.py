@@ -163,8 +163,10 @@ def test_sampling_loop_with_refiner_at_32_songs(monkeypatch):
     g = torch.Generator().manual_seed(2025)
     lat = [[torch.randn(songs, 1152, generator=g) for _ in range(4)] for _ in range(length)]
     want_roll, raw = S.sample_phrases(gsd, lat, length, songs, refiner=True)
-    plain_roll, _ = S.sample_phrases(gsd, lat, length, songs, refiner=False)
-    assert not torch.equal(want_roll, plain_roll), "the refiner must matter for this check to mean anything"
+    with torch.no_grad():           # the refiner must matter for this check to mean anything
+        first_plain = R.generator_sample(gsd, lat[0][0], torch.zeros(songs, 1, 96, 60), torch.zeros(songs, 1, 384, 60),
+                                         torch.full((songs,), 330, dtype=torch.long))
+    assert float((first_plain - raw[0]).abs().max()) > 1e-2
     pre_phrase = torch.zeros(songs, 1, 384, 60); pre_bar = torch.zeros(songs, 1, 96, 60)
     phrase_idx = [330] + list(range(length - 2, -1, -1))
     n = 0

@@ -333,6 +333,79 @@ def test_chained_blocks_equal_the_per_op_path(storage):
         HF.set_compute_dtype("f32")
 
 
+def test_chained_ends_equal_the_per_op_path():
+    """the chains outside the island -- the latent / feature discriminators' MLPs (hipops.blocks.mlp) and an encoder trunk's
+    entry (both stems + the layout change, hipops.blocks.trunk_entry) -- against the per-op path on the same inputs: same
+    entry points in the same order, so forward values are bit-identical and gradients agree to atomic summation order;
+    trainable and frozen (the generator step back-propagates THROUGH frozen discriminators), dense and column-sliced inputs."""
+    from graph.encoder import Encoder
+    from graph.z_discriminator import BarZDiscriminator
+    from graph.bar_discriminator_with_feature import BarFeatureDiscriminator
+    from hipops import FlatParams
+    from hipops import blocks as HB
+    from hipops import functional as HF
+    fork_min = HF.FORK_MIN_BATCH
+    HF.FORK_MIN_BATCH = 1
+    try:
+        for name, mk in (("zdisc", BarZDiscriminator), ("feature", BarFeatureDiscriminator)):
+            torch.manual_seed(5)
+            m = mk().to(dev)
+            with torch.no_grad():           # (the reference's N(-1, 1) init leaves every ReLU dead: nothing to compare)
+                for prm in m.parameters():
+                    prm.copy_(torch.randn_like(prm) * (2.0 / prm.shape[-1] ** 0.5 if prm.dim() > 1 else 0.1))
+            opt = FlatParams(list(m.parameters()))
+            wide = torch.randn(6, 2304)
+            for sliced in (False, True):
+                for frozen in (False, True):
+                    for prm in m.parameters():
+                        prm.requires_grad = not frozen
+                    res = {}
+                    for chained in (False, True):
+                        HB.ENABLED = chained
+                        opt.zero_grad()
+                        wd = wide.to(dev).requires_grad_(True)
+                        x = wd[:, 1152:] if sliced else wd[:, :1152].contiguous()
+                        y = m(x)
+                        assert ("Mlp" in type(y.grad_fn).__name__) == chained
+                        (y * torch.linspace(-1, 2, y.numel(), device=dev).view_as(y)).sum().backward()
+                        torch.cuda.synchronize()
+                        res[chained] = (y.detach().clone(), wd.grad.clone(), opt.grad.clone())
+                    assert float((res[False][0] - res[True][0]).abs().max()) <= 1e-6, (name, sliced, frozen)
+                    for a, b in ((res[False][1], res[True][1]), (res[False][2], res[True][2])):
+                        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), (name, sliced, frozen)
+                    assert (float(res[True][2].abs().max()) == 0.0) == frozen
+                    assert float(res[True][1].abs().max()) > 0
+        for storage in ("f32", "bf16"):
+            HF.set_compute_dtype(storage)
+            torch.manual_seed(6)
+            enc = Encoder([64, 128, 256, 512, 1024]).to(dev)
+            with torch.no_grad():
+                for prm in enc.parameters():
+                    if prm.dim() > 1:
+                        prm.mul_(0.05).add_(0.01 * torch.randn_like(prm))
+            opt = FlatParams(list(enc.parameters()))
+            x = (torch.rand(3, 1, 96, 60) < 0.1).float().to(dev)
+            res = {}
+            for chained in (False, True):
+                HB.ENABLED = chained
+                opt.zero_grad()
+                z = enc(x)
+                z.backward(torch.linspace(-1, 1, z.numel(), device=dev).view_as(z))
+                torch.cuda.synchronize()
+                res[chained] = (z.detach().clone(), opt.grad.clone())
+            # (the NCHW stem convs may split K with fp32 atomics: forward values agree to summation order, not bit for bit;
+            # in bf16 storage that noise can move a bf16 rounding somewhere along the trunk)
+            ztol = (1e-5 if storage == "f32" else 2e-2) * float(res[False][0].abs().max())
+            assert float((res[False][0] - res[True][0]).abs().max()) <= ztol, (storage, float((res[False][0] - res[True][0]).abs().max()))
+            gs = float(res[False][1].abs().max())
+            assert float((res[False][1] - res[True][1]).abs().max()) <= (1e-4 if storage == "f32" else 2e-2) * gs, (
+                storage, float((res[False][1] - res[True][1]).abs().max()) / gs)
+    finally:
+        HB.ENABLED = True
+        HF.FORK_MIN_BATCH = fork_min
+        HF.set_compute_dtype("f32")
+
+
 BF16_BLOCKS = ["residual64", "pooling64", "residual128", "residual512", "pooling512", "deconv_pp1024", "deconv_pp512", "deconv256", "deconv128"]
 
 
@@ -453,6 +526,75 @@ def test_conv_transpose_channels_last_autograd(g):
 def _rel(a, b):
     a = a.detach().double().cpu(); b = b.detach().double().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("g", [(3, 64, 20, 30, 64), (2, 128, 12, 15, 128), (2, 64, 9, 8, 192), (1, 32, 40, 17, 96), (5, 64, 3, 30, 64),
+                               (2, 256, 12, 8, 256)], ids=lambda g: "x".join(map(str, g)))
+def test_nhwc_x3_halo_form(g):
+    """the halo form of the 3x3 stride-1 x3 convs (csrc/conv_nhwc_x3_halo.inc: one zero-padded activation patch per channel
+    block, the nine taps as constant row shifts) forced through the raw C ABI (MGVAE_X3_FORCE=12 / 14), forward and data
+    gradient, against fp64 at the family's fp32-grade bar (2e-5 of the largest entry) and against the implicit-GEMM form on
+    the same operands: odd widths (a tile then starts mid-row and the last tile of a sample is ragged), several samples
+    (tiles never straddle two samples), Cx != Cy, bias + ReLU, the activation-gradient mask, channel slices on both sides."""
+    import os
+    from hipops import _native as nat
+    L = nat.lib()
+    N, Cx, H, W_, Cy = g
+    k, s, p = 3, 1, 1
+    x = torch.randn(N, Cx, H, W_).relu_() * torch.logspace(-2, 2, Cx).view(1, Cx, 1, 1)
+    w = (torch.randn(Cy, Cx, k, k) * 0.2 - 0.03) / torch.logspace(-2, 2, Cx).view(1, Cx, 1, 1)
+    b = torch.randn(Cy)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.double(), stride=s, padding=p)
+    dy = torch.randn_like(yr).float()
+    yr.backward(dy.double())
+    xd, wd, dyd = cl(x), cl(w), cl(dy)
+    nw = Cy * k * k * Cx
+    wk3 = torch.empty(3 * nw, device=dev, dtype=torch.bfloat16); wt3 = torch.empty(3 * nw, device=dev, dtype=torch.bfloat16)
+    assert L.mgvae_pack_conv_weights_x3(vp(wd), vp(wk3), vp(wt3), Cy, k * k, Cx, stream()) == 0
+    d = nat.ConvDesc(N, Cx, H, W_, Cy, H, W_, k, k, s, s, p, p, Cx, 0, Cy, 0, 0, 0.0)
+    # slices: x inside a wider tensor (offset 4), y into a wider tensor (offset 8), with bias + ReLU
+    d2 = nat.ConvDesc(N, Cx, H, W_, Cy, H, W_, k, k, s, s, p, p, Cx + 8, 4, Cy + 12, 8, 1, 0.0)
+    wide_x = cl(torch.randn(N, Cx + 8, H, W_)); wide_x[:, 4:4 + Cx] = xd
+    mask_src = cl(torch.randn(N, Cx, H, W_))                      # dgrad epilogue mask: relu'(mask_src)
+    m = nat.ActMask(mask_src.data_ptr(), Cx, 0, 1, 0.0)
+    got = {}
+    try:
+        for tile in (12, 14, 15, 8):
+            os.environ["MGVAE_X3_FORCE"] = "%d,1" % tile
+            y = cl(torch.full((N, Cy, H, W_), 3.0))
+            assert L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), vp(b.to(dev)), vp(y), None, None, 0, stream()) == 0
+            dx = cl(torch.full((N, Cx, H, W_), 3.0))
+            assert L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(dyd), vp(wt3), None, vp(dx), None, None, 0, stream()) == 0
+            wide_y = cl(torch.full((N, Cy + 12, H, W_), 7.0))
+            assert L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d2), vp(wide_x), vp(wk3), vp(b.to(dev)), vp(wide_y), None, None, 0, stream()) == 0
+            dxm = cl(torch.zeros(N, Cx, H, W_))
+            assert L.mgvae_conv2d_nhwc_x3_bwd_data(ctypes.byref(d), vp(dyd), vp(wt3), None, vp(dxm), ctypes.byref(m), None, 0, stream()) == 0
+            torch.cuda.synchronize()
+            got[tile] = (y.cpu(), dx.cpu(), wide_y.cpu(), dxm.cpu())
+            assert _rel(y, yr) <= 2e-5, (tile, "fwd", _rel(y, yr))
+            assert _rel(dx, xr.grad) <= 2e-5, (tile, "dx", _rel(dx, xr.grad))
+            assert _rel(wide_y[:, 8:8 + Cy], F.relu(yr)) <= 2e-5, (tile, "sliced fwd")
+            assert bool((wide_y[:, :8] == 7).all()) and bool((wide_y[:, 8 + Cy:] == 7).all()), "wrote outside its channel slice"
+            assert _rel(dxm, xr.grad * (mask_src.cpu().double() > 0)) <= 2e-5, (tile, "masked dx")
+            REPORT.append("x3 halo-form check %-22s tile %2d  fwd %.2e  dx %.2e" % (g, tile, _rel(y, yr), _rel(dx, xr.grad)))
+    finally:
+        os.environ.pop("MGVAE_X3_FORCE", None)
+    for tile in (12, 14, 15):      # against the implicit-GEMM form: same products, another summation order over K
+        for a, bref in zip(got[tile], got[8]):
+            assert float((a - bref).abs().max()) <= 1e-5 * float(bref.abs().max()), tile
+    # where the form does not apply (stride 2; W + 2 > 32) a forced halo id falls back to an implicit-GEMM form
+    os.environ["MGVAE_X3_FORCE"] = "12,1"
+    try:
+        dn = nat.ConvDesc(2, 64, 10, 40, 64, 10, 40, 3, 3, 1, 1, 1, 1, 64, 0, 64, 0, 0, 0.0)
+        xn = torch.randn(2, 64, 10, 40); wn = torch.randn(64, 64, 3, 3) * 0.1
+        wkn = torch.empty(3 * wn.numel(), device=dev, dtype=torch.bfloat16); wtn = torch.empty_like(wkn)
+        assert L.mgvae_pack_conv_weights_x3(vp(cl(wn)), vp(wkn), vp(wtn), 64, 9, 64, stream()) == 0
+        yn = cl(torch.zeros(2, 64, 10, 40))
+        assert L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(dn), vp(cl(xn)), vp(wkn), None, vp(yn), None, None, 0, stream()) == 0
+        assert _rel(yn, F.conv2d(xn.double(), wn.double(), None, 1, 1)) <= 2e-5
+    finally:
+        os.environ.pop("MGVAE_X3_FORCE", None)
 
 
 @pytest.mark.parametrize("fam", ["x3", "bf16"])

@@ -13,7 +13,8 @@ B = int(os.environ.get("BENCH_B", "64"))
 CASES = [  # name, N, Cx, H, W, Cy, k, s, p
     ("res64 192x30", B, 64, 192, 30, 64, 3, 1, 1), ("res128 96x15", B, 128, 96, 15, 128, 3, 1, 1),
     ("res256 48x8", B, 256, 48, 8, 256, 3, 1, 1), ("res512 24x4", B, 512, 24, 4, 512, 3, 1, 1),
-    ("res64 48x30 (2B)", 2 * B, 64, 48, 30, 64, 3, 1, 1), ("res512 6x4 (2B)", 2 * B, 512, 6, 4, 512, 3, 1, 1),
+    ("res64 48x30 (2B)", 2 * B, 64, 48, 30, 64, 3, 1, 1), ("res128 24x15 (2B)", 2 * B, 128, 24, 15, 128, 3, 1, 1),
+    ("res256 12x8 (2B)", 2 * B, 256, 12, 8, 256, 3, 1, 1), ("res512 6x4 (2B)", 2 * B, 512, 6, 4, 512, 3, 1, 1),
     ("pool64->128 192x30", B, 64, 192, 30, 128, 3, 2, 1), ("pool256->512 48x8", B, 256, 48, 8, 512, 3, 2, 1),
     ("pool512->1024 24x4", B, 512, 24, 4, 1024, 3, 2, 1),
     ("convT4x4 1024->512 12x7", B, 512, 12, 7, 1024, 4, 2, 1), ("convT4x4 256->128 48x30", B, 128, 48, 30, 256, 4, 2, 1),

@@ -70,9 +70,14 @@ if out:
         w.writeheader()
         w.writerows(rows)
     import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_tag
+    rec = {r["kernel"]: {"hbm_bytes_per_launch": int((r["read_x2_MB"] + r["write_MB"]) * 1e6), "mfma_busy": r["mfma_busy"],
+                         "avg_us": r["avg_us"], "launches": r["launches"]} for r in rows}
+    # which kernels these counters belong to: bench.py only quotes them for a library built from the same sources
+    rec["_kernel_source_tag"] = kernel_source_tag()
     with open(os.path.splitext(out)[0] + ".json", "w") as f:   # what bench.py's roofline.traffic reads
-        json.dump({r["kernel"]: {"hbm_bytes_per_launch": int((r["read_x2_MB"] + r["write_MB"]) * 1e6), "mfma_busy": r["mfma_busy"],
-                                 "avg_us": r["avg_us"], "launches": r["launches"]} for r in rows}, f, indent=1, sort_keys=True)
+        json.dump(rec, f, indent=1, sort_keys=True)
 print(" ".join("%-12s" % c if c != "kernel" else "%-44s" % c for c in cols))
 for r in rows[:40]:
     print(" ".join(("%-44s" % str(r[c])[:44]) if c == "kernel" else "%-12s" % r[c] for c in cols))

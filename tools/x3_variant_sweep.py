@@ -28,7 +28,7 @@ for (N, Cx, H, W, Cy, k, st, p) in GEOMS:
     xd, wd, dyd = cl(x), cl(w), cl(dy)
     wk3 = torch.empty(3 * w.numel(), device=dev, dtype=torch.bfloat16); wt3 = torch.empty_like(wk3)
     assert L.mgvae_pack_conv_weights_x3(vp(wd), vp(wk3), vp(wt3), Cy, k * k, Cx, s) == 0
-    for tile, split in itertools.product(range(12), (1, 2, 5)):      # split: wgrad pixel splits AND the forward / data gradient's deterministic split-K
+    for tile, split in itertools.product(range(16), (1, 2, 5)):      # split: wgrad pixel splits AND the forward / data gradient's deterministic split-K
         os.environ["MGVAE_X3_FORCE"] = "%d,%d" % (tile, split)
         yd = cl(torch.zeros(N, Cy, OH, OW)); dx = cl(torch.zeros(N, Cx, H, W)); dw = cl(torch.zeros(Cy, Cx, k, k))
         rc = [L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), None, vp(yd), None, WS_P, WS_N, s),
