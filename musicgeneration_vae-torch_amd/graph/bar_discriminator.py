@@ -8,6 +8,7 @@ BatchNorm2d uses per-process batch statistics (like the reference under nn.DataP
 from torch import nn
 
 from hipops import functional as HF
+from hipops import netchain as NC
 from graph.layers import BatchNorm2d, Conv2d, Linear
 from graph.weights_initializer import weights_init
 
@@ -124,9 +125,15 @@ class BarDiscriminator(nn.Module):
         self.linear = Linear(64 * 3, 1, bias=False)
         self.apply(weights_init)
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_mg_chain_cache", None)       # .to() / .cuda() re-create the buffers the launch chain points at
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, x):
         import torch
         x = x.reshape(-1, 1, 96 * 2, 60)
+        if NC.usable(self, x):
+            return NC.bar_discriminator(self, x)      # the three towers as one autograd node and one launch chain per direction
         n = x.shape[0]
         feat = torch.empty((n, 192), device=x.device, dtype=torch.float32)
         a = HF.copy_into(self.chord(x), feat[:, :64])

@@ -36,7 +36,7 @@ def oracle_step(gsd64, enc_inputs, phrase, decode, loss_of):
     return {n: bound[n].detach() for n in names}, dict(zip(names, grads)), float(loss)
 
 
-def _run_segment(tag, hip_fn, oracle_fn, osd, hip_params, opt, inputs, in_grads, dy, out_ref, tol):
+def _run_segment(tag, hip_fn, oracle_fn, osd, hip_params, opt, inputs, in_grads, dy, out_ref, tol, l2_ok=None):
     """one segment.  inputs: list of fp64 tensors (int tensors pass through); in_grads: the oracle's gradients of those
     inputs (None: not checked); dy: the oracle's gradient of the segment output; osd: fresh fp64 leaves of its parameters.
     Returns ({parameter name within the segment: rule}, {input index: rule})"""
@@ -55,7 +55,7 @@ def _run_segment(tag, hip_fn, oracle_fn, osd, hip_params, opt, inputs, in_grads,
     dx_rules, p_rules = {}, {}
     for i, (t, g) in enumerate(zip(xd, in_grads)):
         if g is not None:
-            dx_rules[i] = check_grad("%s dx%d" % (tag, i), t.grad, g, 2 * tol)
+            dx_rules[i] = check_grad("%s dx%d" % (tag, i), t.grad, g, 2 * tol, l2_ok=l2_ok)
     gs = max([v.grad.abs().max().item() for v in osd.values() if v.grad is not None] + [1e-300])
     for n, p in hip_params.items():
         og = osd[n].grad
@@ -64,7 +64,7 @@ def _run_segment(tag, hip_fn, oracle_fn, osd, hip_params, opt, inputs, in_grads,
             continue
         if og.abs().max().item() <= 1e-6 * gs:
             continue
-        p_rules[n] = check_grad("%s d%s" % (tag, n), p.grad, og, 2 * tol, atol=1e-6 * gs)
+        p_rules[n] = check_grad("%s d%s" % (tag, n), p.grad, og, 2 * tol, atol=1e-6 * gs, l2_ok=l2_ok)
     return p_rules, dx_rules
 
 
@@ -81,9 +81,14 @@ def segmented_generator_check(gen, opt, gsd, bound, grads, position, masks, enc_
     def params_of(module):
         return dict(module.named_parameters())
 
-    def seg(name, module, hip_fn, oracle_fn, prefix, inputs, in_grads, dy, out_ref):
+    def seg(name, module, hip_fn, oracle_fn, prefix, inputs, in_grads, dy, out_ref, island=False):
+        # ``tol`` is the bound of the segments INSIDE the channels-last island (it differs from TOL only in bf16 storage);
+        # the stems, heads, Linears and fit2 compute in fp32 in every mode
         osd = _leaf(gsd, prefix)
-        p_rules, dx_rules = _run_segment(name, hip_fn, oracle_fn, osd, params_of(module), opt, inputs, in_grads, dy, out_ref, tol)
+        # bf16 storage (tol > TOL): a row of an island segment that misses the max-norm bound may still pass on its relative L2
+        # error (<= 5e-2): a small aggregate such as a CBAM gate-MLP weight sums bf16-rounded terms over whole maps
+        p_rules, dx_rules = _run_segment(name, hip_fn, oracle_fn, osd, params_of(module), opt, inputs, in_grads, dy, out_ref,
+                                         tol if island else TOL, l2_ok=5e-2 if (island and tol > TOL) else None)
         for n, v in p_rules.items():
             report[prefix + n] = v
         for i, v in dx_rules.items():
@@ -105,7 +110,7 @@ def segmented_generator_check(gen, opt, gsd, bound, grads, position, masks, enc_
             ofn = R.residual_module if i % 2 == 0 else R.pooling_module
             out_ref, out_g = bound[p + "layers.%d" % i], grads[p + "layers.%d" % i]
             seg(p + "layers.%d" % i, blk, (lambda x, blk=blk: HF.to_nchw(blk(cl(x)))) if trunk.channels_last else blk,
-                lambda sd, x, ofn=ofn: ofn(sd, "", x), p + "layers.%d." % i, [prev], [prev_g], out_g, out_ref)
+                lambda sd, x, ofn=ofn: ofn(sd, "", x), p + "layers.%d." % i, [prev], [prev_g], out_g, out_ref, island=True)
             prev, prev_g = out_ref, out_g
         key = "zz" if p == "encoder." else "pf"
         seg(p + "linear", trunk.linear, lambda x, t=trunk: t.linear(HF.global_avg_pool(x)),
@@ -145,12 +150,13 @@ def segmented_generator_check(gen, opt, gsd, bound, grads, position, masks, enc_
             self.fit1, self.bn, self.cbam = d.fit1, d.bn, d.cbam
     wrap = (lambda f: (lambda x: HF.to_nchw(f(cl(x))))) if dec.channels_last else (lambda f: f)
     seg(p + "fit1", Fit(dec), wrap(dec.fit_stage), lambda sd, x: R.decoder_fit1(sd, "", x), p, [cat_ref], [cat_grad],
-        grads[p + "fit1"], bound[p + "fit1"])
+        grads[p + "fit1"], bound[p + "fit1"], island=True)
     prev, prev_g = bound[p + "fit1"], grads[p + "fit1"]
     for i, blk in enumerate(dec.layers):
         ofn = R.deconv_pitch_padding if i < 2 else R.deconv_module
         out_ref, out_g = bound[p + "layers.%d" % i], grads[p + "layers.%d" % i]
-        seg(p + "layers.%d" % i, blk, wrap(blk), lambda sd, x, ofn=ofn: ofn(sd, "", x), p + "layers.%d." % i, [prev], [prev_g], out_g, out_ref)
+        seg(p + "layers.%d" % i, blk, wrap(blk), lambda sd, x, ofn=ofn: ofn(sd, "", x), p + "layers.%d." % i, [prev], [prev_g], out_g, out_ref,
+            island=True)
         prev, prev_g = out_ref, out_g
     seg(p + "fit2", dec.fit2, lambda x: dec.fit2(x, act=HF.ACT_SIGMOID), lambda sd, x: torch.sigmoid(F.conv2d(x, sd["weight"])),
         p + "fit2.", [prev], [prev_g], grads["gen"], bound["gen"])

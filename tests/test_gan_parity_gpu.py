@@ -352,6 +352,59 @@ def _oracle(kind, sds, lr, batch, noise, masks, dtype, perturb=None):
     return o, osd
 
 
+def test_bf16_generator_step_segmented_against_rounding_oracle():
+    """BASELINE.json configs 2-3 (bf16 storage inside the island): the pre-training generator step cut at the block
+    boundaries like the fp32 one (tests/segmented.py), every segment in bf16 STORAGE against the fp64 oracle under the
+    island's rounding model (oracle.restate.ISLAND_ROUNDING), teacher-forced on that oracle's activations and activation
+    gradients.  Through ~40 layers the whole bf16 step is chaotic at bf16 resolution (the round-2 whole-step test can only
+    ask for "as close to the rounding oracle as that is to exact arithmetic", i.e. ~0.2); one segment is not: forward within
+    1e-2 of the largest activation, input and parameter gradients within 2e-2 of the tensor's largest entry (the per-block
+    tests measure 2e-3 / 3-7e-3), the fp32 segments outside the island (stems, heads, Linears, fit2) at the fp32 bounds."""
+    import segmented as SG
+    from graph.model import Model
+    from hipops import FlatParams
+    from hipops import functional as HF
+    from parity_util import RoundBf16, RoundBf16Forward
+    B = 4
+    gsd = W.make_state_dict(W.manifest_generator(), 0, "wc")
+    zb = {k: v.double() for k, v in W.make_state_dict(W.manifest_z_discriminator(), 1, "wc").items()}
+    zp = {k: v.double() for k, v in W.make_state_dict(W.manifest_z_discriminator(), 2, "wc").items()}
+    note, pre_note, pre_phrase, position = W.make_inputs(B, seed=61)
+    masks = [m.double() for m in _masks(B, 9)]
+    ones = torch.ones(B, dtype=torch.float64)
+    HF.set_compute_dtype("bf16")
+    R.ISLAND_ROUNDING = (RoundBf16.apply, RoundBf16Forward.apply)
+    try:
+        gen = Model()
+        gen.load_state_dict(gsd)
+        gen = gen.to(dev).train()
+        opt = FlatParams(list(gen.parameters()))
+        g64 = {k: v.double().requires_grad_(True) for k, v in gsd.items()}
+
+        def decode(zz, pf, taps):
+            return R.decoder(g64, "decoder.", zz[:B], zz[B:], pf, position, True, masks, taps)
+
+        def loss_of(g, zz, pf):
+            loss = R.dloss(R.z_discriminator(zp, "", pf).view(-1), ones)
+            loss = loss + R.dloss(R.z_discriminator(zb, "", zz[:B]).view(-1), ones) + R.dloss(R.z_discriminator(zb, "", zz[B:]).view(-1), ones)
+            return loss + R.bar_loss(g, note.double(), True)
+
+        enc_in = torch.cat((note, pre_note), 0).double()
+        bound, gr, _ = SG.oracle_step(g64, enc_in, pre_phrase.double(), decode, loss_of)
+        bound["__enc_in"], bound["__phrase_in"] = enc_in, pre_phrase.double()
+        rep = SG.segmented_generator_check(gen, opt, gsd, bound, gr, position, masks, B=B, tol=1e-2)
+    finally:
+        R.ISLAND_ROUNDING = None
+        HF.set_compute_dtype("f32")
+    rules = {k: v for k, v in rep.items() if ":dx" not in k}
+    bad = sorted((k, v) for k, v in rules.items() if v != "strict")
+    REPORT.append("bf16 pre-training generator step, segmented vs the rounding oracle: %d parameter rows + %d boundary gradients; "
+                  "not within 2e-2 in max norm (admitted on relative L2 <= 5e-2 or as <= 2 %% outliers): %s" % (len(rules), len(rep) - len(rules), bad))
+    # every row passed one of: 2e-2 max-norm, <= 2 % outliers with L2 <= 5e-2, L2 <= 5e-2 (island rows only): i.e. every row of the
+    # bf16 step is within 5e-2 of the rounding oracle once its segment boundaries are pinned -- the whole step's bound was ~0.3
+    assert len(rules) >= 180 and len(bad) <= 0.25 * len(rules), bad
+
+
 def _segmented_wae_generator_step(agent, sds, osd, batch, masks):
     """the generator step of the WAE iteration (agent/barGen_with_gan.py:426-452), cut at the block boundaries: the HIP
     generator holds the INITIAL weights (this runs before the agent's own iteration), the latent discriminators are the

@@ -375,6 +375,48 @@ def test_chained_ends_equal_the_per_op_path():
                         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), (name, sliced, frozen)
                     assert (float(res[True][2].abs().max()) == 0.0) == frozen
                     assert float(res[True][1].abs().max()) > 0
+        # the bar-pair discriminator (hipops/netchain.py): train / eval BatchNorm, trainable / frozen, gradient into the pair or not
+        from graph.bar_discriminator import BarDiscriminator
+        for training in (True, False):
+            for frozen in (False, True):
+                for need_dx in (False, True):
+                    if frozen and not need_dx:
+                        continue
+                    res = {}
+                    for chained in (False, True):
+                        HB.ENABLED = chained
+                        torch.manual_seed(7)
+                        m = BarDiscriminator().to(dev)
+                        with torch.no_grad():
+                            for prm in m.parameters():
+                                if prm.dim() > 1:
+                                    prm.copy_(torch.randn_like(prm) * (1.5 / (prm[0].numel() ** 0.5)))
+                            for mod in m.modules():
+                                if type(mod).__name__ == "BatchNorm2d":
+                                    mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+                        m.train(training)
+                        for prm in m.parameters():
+                            prm.requires_grad = not frozen
+                        opt = FlatParams(list(m.parameters()))
+                        opt.zero_grad()
+                        x = (torch.rand(5, 1, 192, 60, generator=torch.Generator().manual_seed(3)) < 0.1).float().to(dev).requires_grad_(need_dx)
+                        y = m(x)
+                        assert ("BarDisc" in type(y.grad_fn).__name__) == chained
+                        (y * torch.linspace(-1, 2, y.numel(), device=dev).view_as(y)).sum().backward()
+                        torch.cuda.synchronize()
+                        sd = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+                        res[chained] = (y.detach().clone(), x.grad.clone() if need_dx else None, opt.grad.clone(), sd)
+                    (y0, dx0, g0, sd0), (y1, dx1, g1, sd1) = res[False], res[True]
+                    tag = ("bar discriminator", training, frozen, need_dx)
+                    assert float((y0 - y1).abs().max()) <= 1e-6, tag
+                    assert float((g0 - g1).abs().max()) <= 1e-5 * max(float(g0.abs().max()), 1e-30), tag
+                    assert (float(g1.abs().max()) == 0.0) == frozen, tag
+                    if need_dx:
+                        assert float(dx0.abs().max()) > 0 and float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx0.abs().max()), tag
+                    for k in sd0:
+                        assert float((sd0[k].double() - sd1[k].double()).abs().max()) <= 1e-6 * max(1.0, float(sd0[k].double().abs().max())), (tag, k)
+                    assert int(sd1["chord.batch_norm1.num_batches_tracked"]) == (1 if training else 0)
+                    assert int(sd1["basic.layers.2.bn1.num_batches_tracked"]) == 0
         for storage in ("f32", "bf16"):
             HF.set_compute_dtype(storage)
             torch.manual_seed(6)
