@@ -57,14 +57,19 @@ def _run_segment(tag, hip_fn, oracle_fn, osd, hip_params, opt, inputs, in_grads,
         if g is not None:
             dx_rules[i] = check_grad("%s dx%d" % (tag, i), t.grad, g, 2 * tol, l2_ok=l2_ok)
     gs = max([v.grad.abs().max().item() for v in osd.values() if v.grad is not None] + [1e-300])
+    # analytically-zero gradients (the bias of a conv in front of an InstanceNorm) are pure rounding noise: 1e-6 of the
+    # segment's largest gradient entry in fp32, 5e-3 of it where the segment's tensors are STORED in bf16 (l2_ok is only
+    # given for those segments) -- such rows carry no information and are skipped, smaller entries of other rows get the
+    # same absolute allowance
+    floor = (5e-3 if l2_ok is not None else 1e-6) * gs
     for n, p in hip_params.items():
         og = osd[n].grad
         if og is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, (tag, n)      # D5: never used
             continue
-        if og.abs().max().item() <= 1e-6 * gs:
+        if og.abs().max().item() <= floor:
             continue
-        p_rules[n] = check_grad("%s d%s" % (tag, n), p.grad, og, 2 * tol, atol=1e-6 * gs, l2_ok=l2_ok)
+        p_rules[n] = check_grad("%s d%s" % (tag, n), p.grad, og, 2 * tol, atol=floor, l2_ok=l2_ok)
     return p_rules, dx_rules
 
 

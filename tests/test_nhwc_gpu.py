@@ -622,6 +622,25 @@ def test_nhwc_x3_halo_form(g):
             REPORT.append("x3 halo-form check %-22s tile %2d  fwd %.2e  dx %.2e" % (g, tile, _rel(y, yr), _rel(dx, xr.grad)))
     finally:
         os.environ.pop("MGVAE_X3_FORCE", None)
+    # the weight gradient with the nine taps inside the workgroup (same file: K over the zero-padded positions, taps as row
+    # shifts of the X operand's transposing reads); forced id 12 = that form wherever Cx and Cy are multiples of 64
+    try:
+        dws = {}
+        for tile, split in ((12, 1), (12, 3), (8, 2)):
+            os.environ["MGVAE_X3_FORCE"] = "%d,%d" % (tile, split)
+            dw = cl(torch.zeros(Cy, Cx, k, k))
+            assert L.mgvae_conv2d_nhwc_x3_bwd_weight(ctypes.byref(d), vp(xd), vp(dyd), vp(dw), stream()) == 0
+            # and ACCUMULATING into a non-zero gradient, from a channel slice of a wider activation tensor
+            dw2 = cl(torch.ones(Cy, Cx, k, k))
+            dsl = nat.ConvDesc(N, Cx, H, W_, Cy, H, W_, k, k, s, s, p, p, Cx + 8, 4, Cy, 0, 0, 0.0)
+            assert L.mgvae_conv2d_nhwc_x3_bwd_weight(ctypes.byref(dsl), vp(wide_x), vp(dyd), vp(dw2), stream()) == 0
+            torch.cuda.synchronize()
+            assert _rel(dw, wr.grad) <= 2e-5, (tile, split, "dw", _rel(dw, wr.grad))
+            assert _rel(dw2 - 1.0, wr.grad) <= 2e-5, (tile, split, "dw accumulate / slice")
+            dws[(tile, split)] = dw.cpu()
+            REPORT.append("x3 weight gradient %-22s forced %2d,%d  dw %.2e" % (g, tile, split, _rel(dw, wr.grad)))
+    finally:
+        os.environ.pop("MGVAE_X3_FORCE", None)
     for tile in (12, 14, 15):      # against the implicit-GEMM form: same products, another summation order over K
         for a, bref in zip(got[tile], got[8]):
             assert float((a - bref).abs().max()) <= 1e-5 * float(bref.abs().max()), tile
