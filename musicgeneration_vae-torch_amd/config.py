@@ -26,6 +26,7 @@ class Config(object):
     seed = None               # None -> random.randint(1, 10000) like the reference
     grad_bucket_mb = 64       # RCCL all-reduce bucket size
     log_file = 'train_epoch.log'
+    num_workers = 1           # loader workers like the reference (agent/barGen2.py:41); spawned, never forked, persistent; 0 = in-process
     packed_data_file = None   # e.g. 'data/bars_packed.npz' (data.bar_dataset.pack_dataset): bit-packed rolls, expanded on the GPU
     compute_dtype = 'f32'     # 'bf16': bf16 matrix operands / fp32 accumulate in the conv kernels (tensors, master weights
                               # and Adam stay fp32) -- BASELINE.json configs 3-4
