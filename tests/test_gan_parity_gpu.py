@@ -441,6 +441,53 @@ def _segmented_wae_generator_step(agent, sds, osd, batch, masks):
     return rules
 
 
+def _segmented_gan_generator_step(agent, sds, osd, batch, noise, masks):
+    """the generator step of the GAN iteration (agent/barGen_with_gan.py:507-529), cut at the block boundaries like the WAE
+    one: the bar is decoded from the N(0, 1.5^2) latent, judged by the (already updated, frozen, train-mode) bar
+    discriminator on the pair (pre_note, gen) and by the feature discriminator on encoder(gen > 0.3).  The bar encoder runs
+    twice -- on pre_note and on the binarised fake bar, which depends on the decoder's output -- so the oracle step is
+    assembled here and its two encoder passes are stacked along the batch for the segments (the encoder has no
+    cross-sample op)."""
+    import segmented as SG
+    note, pre_note, pre_phrase, position = batch
+    B = note.shape[0]
+    g64 = {k: v.double().requires_grad_(True) for k, v in sds["generator"].items()}
+    dd = {k: (v.detach().clone() if v.is_floating_point() else v.clone()) for k, v in osd["discriminator"].items()}
+    ff = {k: v.detach() for k, v in osd["discriminator_feature"].items()}
+    m64 = [m.double() for m in masks]
+    ones = torch.ones(B, dtype=torch.float64)
+    tp, ta, tb, td = {}, {}, {}, {}
+    pf = R.phrase_model(g64, "phrase_encoder.", pre_phrase.double(), tp)
+    pre_z = R.encoder(g64, "encoder.", pre_note.double(), ta)
+    gen = R.decoder(g64, "decoder.", noise.double(), pre_z, pf, position, True, m64, td)
+    fake = torch.gt(gen, 0.3).to(gen.dtype)
+    gen_z = R.encoder(g64, "encoder.", fake, tb)
+    loss = R.dloss(R.bar_discriminator(dd, "", torch.cat((pre_note.double(), gen), dim=2), train=True).view(-1), ones)
+    loss = loss + R.dloss(R.bar_feature_discriminator(ff, "", gen_z).view(-1), ones)
+    bound = {"pf": pf, "gen": gen, "pre_z": pre_z, "gen_z": gen_z}
+    bound.update(tp); bound.update(td)
+    for k in ta:
+        bound["A:" + k] = ta[k]; bound["B:" + k] = tb[k]
+    names = list(bound)
+    gr = dict(zip(names, torch.autograd.grad(loss, [bound[n] for n in names], allow_unused=True)))
+    zero = lambda t, g: torch.zeros_like(t) if g is None else g
+    b2, g2 = {n: bound[n].detach() for n in names if n[:2] not in ("A:", "B:")}, {n: gr[n] for n in names if n[:2] not in ("A:", "B:")}
+    for k in ta:
+        b2[k] = torch.cat((bound["A:" + k].detach(), bound["B:" + k].detach()), 0)
+        g2[k] = torch.cat((zero(bound["A:" + k], gr["A:" + k]), zero(bound["B:" + k], gr["B:" + k])), 0)
+    b2["zz"] = torch.cat((pre_z.detach(), gen_z.detach()), 0)
+    g2["zz"] = torch.cat((zero(pre_z, gr["pre_z"]), zero(gen_z, gr["gen_z"])), 0)
+    b2["__enc_in"], b2["__phrase_in"] = torch.cat((pre_note.double(), fake.detach()), 0), pre_phrase.double()
+    rep = SG.segmented_generator_check(agent.generator, agent.opt_generator, sds["generator"], b2, g2, position, m64, B=B,
+                                       decoder_latent=noise.double())
+    rules = {k: v for k, v in rep.items() if ":dx" not in k}
+    bad = sorted(k for k, v in rules.items() if v != "strict")
+    REPORT.append("GAN generator step, segmented: %d parameter rows + %d boundary gradients; not strict: %s" % (
+        len(rules), len(rep) - len(rules), bad))
+    assert len(rules) >= 180 and len(bad) <= 0.05 * len(rules), bad
+    return rules
+
+
 def test_train_wae_iteration_against_oracle(tmp_path, monkeypatch):
     agent, sds, grads = _agent(tmp_path, monkeypatch)
     lr = agent.config.learning_rate
@@ -488,9 +535,10 @@ def test_train_gan_iteration_against_oracle(tmp_path, monkeypatch):
     agent.epoch = 1
     from metrics import AverageMeter
     meters = {k: AverageMeter() for k in ("generator", "discriminator", "discriminator_feature", "z_bar", "z_phrase")}
+    o, osd = _oracle("gan", sds, lr, batch, noise, masks, torch.float64)
+    seg = _segmented_gan_generator_step(agent, sds, osd, batch, noise, masks)
     out = agent.train_gan(*(t.to(dev) for t in batch), meters, 0)
     torch.cuda.synchronize()
-    o, osd = _oracle("gan", sds, lr, batch, noise, masks, torch.float64)
     o32, _ = _oracle("gan", sds, lr, batch, noise, masks, torch.float32)
     o32 = _with_perturbed(o32, lambda seed: _oracle("gan", sds, lr, batch, noise, masks, torch.float32, perturb=seed)[0])
     check("train_gan bar discriminator loss", meters["discriminator"].val, o["note_loss"])
@@ -502,7 +550,7 @@ def test_train_gan_iteration_against_oracle(tmp_path, monkeypatch):
     _compare_net("train_gan discriminator_feature", agent.discriminator_feature, grads["discriminator_feature"],
                  o["grad_discriminator_feature"], o32["grad_discriminator_feature"], osd["discriminator_feature"], sds["discriminator_feature"], lr)
     _compare_net("train_gan generator", agent.generator, grads["generator"], o["grad_generator"], o32["grad_generator"], osd["generator"],
-                 sds["generator"], lr)
+                 sds["generator"], lr, segment=seg)
     pop_margins("train_gan iteration vs fp64 oracle", 10)
     # BatchNorm running statistics after THREE train-mode passes (fake, real, generator step) and their counters
     hsd = agent.discriminator.state_dict()
