@@ -180,9 +180,12 @@ class Decoder(nn.Module):
         return self.cbam.fused_norm(self.fit1(o), self.bn, 1, act=HF.ACT_RELU, channels_last=self.channels_last)
 
     def forward(self, z, pre_z, phrase_feature, position):
-        o = self.stems(self.head(z, pre_z, phrase_feature, position))
-        if self.channels_last:
-            o = HF.to_channels_last(o)
+        if self.channels_last and HB.front_usable(z):
+            o = HB.decoder_front(self, z, pre_z, phrase_feature, position)     # head + stems + layout change: one node
+        else:
+            o = self.stems(self.head(z, pre_z, phrase_feature, position))
+            if self.channels_last:
+                o = HF.to_channels_last(o)
         o = self.fit_stage(o)
         for blk in self.layers:
             o = blk(o)

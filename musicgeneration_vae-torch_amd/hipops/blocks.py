@@ -726,3 +726,224 @@ def trunk_entry(x, trunk):
 def entry_usable(x):
     return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 1 and not x.requires_grad
             and HF.get_nchw_operand_dtype() == "f32" and not HF.USE_DIRECT)
+
+
+# ============================================================================ decoder: head + stems + layout change
+class _DecoderFrontFn(torch.autograd.Function):
+    """graph/decoder.py:192-211 as one node: the two Linear + ReLU + Dropout branches over (phrase feature, position embedding)
+    and (z, pre_z), their concat, the two stems (a non-overlapping transposed conv of the 1x1 map = a plain GEMM, a second
+    transposed conv, InstanceNorm, +CBAM, ReLU) side by side, and the layout change into the channels-last island:
+    (z, pre_z, phrase_feature [B,1152], position [B]) -> [B, 2048, 6, 3] channels-last of the island's storage type.
+    ``mode``: 0 no dropout (eval), 1 Philox dropout (seed / offsets passed in), 2 the two given masks (tests)."""
+
+    @staticmethod
+    def forward(ctx, z, pre_z, pf, position, mode, p_drop, seed, offs, dtype, eps, geo, m0, m1, table, Wp, bp, Wb, bb, *stems):
+        HF._need_cuda(z, "decoder front")
+        z, zpt = _pitch2d(z)
+        pre_z, pzpt = _pitch2d(pre_z)
+        pf, pfpt = _pitch2d(pf)
+        position = position.to(device=z.device, dtype=torch.int64).contiguous()
+        B = z.shape[0]
+        st = HF.STORE_BF16 if dtype == torch.bfloat16 else HF.STORE_F32
+        L = nat.lib()
+        tw = bool(HF.USE_TRANSPOSED_W)
+        key = ("dfront-f", B, zpt, pzpt, pfpt, mode, geo, st, float(eps), float(p_drop), tw)
+        e = _chains.get(key)
+        NC, P = B * 1024, 18
+        if e is None:
+            ch = Chain()
+            (s_z, s_pz, s_pf, s_pos, s_seed, s_o0, s_o1, s_m0, s_m1, s_tab, s_Wp, s_bp, s_Wb, s_bb, s_pbuf, s_bbuf, s_xbuf, s_hp, s_hb, s_dp,
+             s_db, s_mk0, s_mk1, s_cat, s_ocl, s_st) = ch.slots(26)
+            n = B * 1152
+            lin = _desc(B, 2304, 1, 1, 1152, 1, 1, (1, 1), (1, 1), (0, 0), 2304, 1152, HF.ACT_RELU, 0.01)
+            ch.call("mgvae_copy2d", s_pbuf, 2304, s_pf, pfpt, 1152, B, s_st)
+            ch.call("mgvae_embedding_fwd", s_pos, s_tab, s_pbuf + 4 * 1152, B, 1152, 332, 2304, s_st)
+            ch.call("mgvae_conv2d_fwd", ch.struct(lin), s_pbuf, s_Wp, s_bp, s_hp, s_st)
+            if mode == 1:
+                ch.call("mgvae_dropout_fwd", s_hp, s_dp, s_mk0, n, p_drop, s_seed, s_o0, s_st)
+            elif mode == 2:
+                ch.call("mgvae_mul", s_hp, s_m0, s_dp, n, s_st)
+            ch.call("mgvae_copy2d", s_bbuf, 2304, s_z, zpt, 1152, B, s_st)
+            ch.call("mgvae_copy2d", s_bbuf + 4 * 1152, 2304, s_pz, pzpt, 1152, B, s_st)
+            ch.call("mgvae_conv2d_fwd", ch.struct(lin), s_bbuf, s_Wb, s_bb, s_hb, s_st)
+            if mode == 1:
+                ch.call("mgvae_dropout_fwd", s_hb, s_db, s_mk1, n, p_drop, s_seed, s_o1, s_st)
+            elif mode == 2:
+                ch.call("mgvae_mul", s_hb, s_m1, s_db, n, s_st)
+            ch.call("mgvae_copy2d", s_xbuf, 2304, s_db if mode else s_hb, 1152, 1152, B, s_st)
+            ch.call("mgvae_copy2d", s_xbuf + 4 * 1152, 2304, s_dp if mode else s_hp, 1152, 1152, B, s_st)
+            shapes = []
+            for si in range(2):
+                (k1, k2) = geo[si]
+                s_w1, s_w2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_wt, s_u, s_stats, s_save = ch.slots(13)
+                co1 = 1024 * k1[0] * k1[1]
+                h1, w1_ = k1
+                if (h1 * k2[0], w1_ * k2[1]) != (6, 3):
+                    raise RuntimeError("decoder stem does not produce a 6 x 3 map")
+                shapes.append((co1, h1, w1_))
+                # 1x1 map through a non-overlapping transposed conv = the GEMM y[n, (co,kh,kw)] = x[n, ci] . w[ci, (co,kh,kw)]
+                ch.call("mgvae_conv2d_bwd_data", ch.struct(_desc(B, co1, 1, 1, 2304, 1, 1, (1, 1), (1, 1), (0, 0), co1, 2304, HF.ACT_RELU, 0.01)),
+                        s_xbuf, s_w1, None, s_t1, s_st)
+                d2 = _desc(B, 1024, 6, 3, 1024, h1, w1_, k2, k2, (0, 0), 1024, 1024, HF.ACT_NONE, 0.01)
+                if tw and k2[0] * k2[1] > 1:
+                    ch.call("mgvae_weight_transpose", s_w2, s_wt, 1024, 1024, k2[0] * k2[1], s_st)
+                    ch.call("mgvae_conv2d_bwd_data_tw", ch.struct(d2), s_t1, s_wt, None, s_t2, s_st)
+                else:
+                    ch.call("mgvae_conv2d_bwd_data", ch.struct(d2), s_t1, s_w2, None, s_t2, s_st)
+                ch.call("mgvae_instance_norm_fwd", s_t2, s_g, s_b, s_u, s_stats, B, 1024, P, 1024, 0, eps, HF.ACT_NONE, 0.0, s_save + 4 * NC,
+                        s_save + 8 * NC, s_save + 12 * NC, s_st)
+                ch.call("mgvae_cbam_fwd", s_u, None, s_c1, s_c2, s_sa, s_cat + 4 * si * 1024 * P, s_save, B, 1024, 6, 3, 2048, 0, 1, HF.ACT_RELU,
+                        0.01, 3 | 4, s_st)
+            ch.call("mgvae_layout_nchw_to_nhwc", s_cat, s_ocl, B, 2048, P, 2048, 0, 2048, 0, st, s_st)
+            e = _chains[key] = (ch.finalize(), shapes, int(L.mgvae_cbam_save_floats(B, 1024, 6, 3)))
+        ch, shapes, nsave = e
+        dev = z.device
+        f = lambda *s_: torch.empty(s_, device=dev, dtype=torch.float32)
+        pbuf, bbuf, xbuf, hp, hb = f(B, 2304), f(B, 2304), f(B, 2304), f(B, 1152), f(B, 1152)
+        dp = f(B, 1152) if mode else None
+        db = f(B, 1152) if mode else None
+        mk0 = f(B, 1152) if mode == 1 else None
+        mk1 = f(B, 1152) if mode == 1 else None
+        cat = f(B, 2048, 6, 3)
+        ocl = HF.new_channels_last(B, 2048, 6, 3, dev, dtype)
+        addr = [z.data_ptr(), pre_z.data_ptr(), pf.data_ptr(), position.data_ptr(), int(seed), int(offs[0]), int(offs[1]), _ptr(m0), _ptr(m1),
+                table.data_ptr(), Wp.data_ptr(), bp.data_ptr(), Wb.data_ptr(), bb.data_ptr(), pbuf.data_ptr(), bbuf.data_ptr(), xbuf.data_ptr(),
+                hp.data_ptr(), hb.data_ptr(), _ptr(dp), _ptr(db), _ptr(mk0), _ptr(mk1), cat.data_ptr(), ocl.data_ptr(), _main()]
+        keep = []
+        for si in range(2):
+            w1, w2, g, b, c1, c2, sa = stems[7 * si:7 * si + 7]
+            co1, h1, w1_ = shapes[si]
+            t1, t2, wt, u, stats, save = f(B, co1), f(B, 1024, 6, 3), f(w2.numel()), f(B, 1024, 6, 3), f(2 * NC), f(nsave)
+            keep += [t1, t2, u, stats, save]
+            addr += [w1.data_ptr(), w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(),
+                     t2.data_ptr(), wt.data_ptr(), u.data_ptr(), stats.data_ptr(), save.data_ptr()]
+        ch.run(addr)
+        masks = (mk0, mk1) if mode == 1 else ((m0, m1) if mode == 2 else (None, None))
+        ctx.save_for_backward(position, table, Wp, bp, Wb, bb, pbuf, bbuf, xbuf, hp, hb, masks[0], masks[1], cat, *stems, *keep)
+        ctx.cfg = (mode, st, geo, shapes, dtype, tw)
+        return ocl
+
+    @staticmethod
+    def backward(ctx, dy):
+        mode, st, geo, shapes, dtype, tw = ctx.cfg
+        sv = ctx.saved_tensors
+        position, table, Wp, bp, Wb, bb, pbuf, bbuf, xbuf, hp, hb, mk0, mk1, cat = sv[:14]
+        stems, keep = sv[14:28], sv[28:]
+        B = xbuf.shape[0]
+        NC, P, NP = B * 1024, 18, B * 18
+        L = nat.lib()
+        flags = tuple(bool(p.requires_grad) for p in (table, Wp, bp, Wb, bb) + tuple(stems))
+        need = tuple(bool(v) for v in ctx.needs_input_grad[:3])
+        key = ("dfront-b", B, mode, geo, st, flags, tw)
+        e = _chains.get(key)
+        if e is None:
+            ch = Chain()
+            (s_pos, s_Wp, s_Wb, s_pbuf, s_bbuf, s_xbuf, s_hp, s_hb, s_mk0, s_mk1, s_cat, s_dy, s_dcat, s_dx0, s_dx1, s_gb, s_gb2, s_dpre_b, s_dbbuf,
+             s_gp, s_gp2, s_dpre_p, s_dpbuf, s_dtab, s_dWp, s_dbp, s_dWb, s_dbb, s_st, s_side) = ch.slots(30)
+            ch.call("mgvae_layout_nhwc_to_nchw", s_dy, s_dcat, B, 2048, P, 2048, 0, 2048, 0, st, s_st)
+            dxs = (s_dx0, s_dx1)
+            for si in range(2):
+                (k1, k2) = geo[si]
+                co1, h1, w1_ = shapes[si]
+                fl = flags[5 + 7 * si:5 + 7 * si + 7]
+                (s_w1, s_w2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_u, s_stats, s_save, s_du, s_dt2, s_dt1, s_scr, s_dw1, s_dw2, s_dg, s_db_,
+                 s_dc1, s_dc2, s_dsa) = ch.slots(23)
+                off = 4 * si * 1024 * P
+                ch.call("mgvae_cbam_bwd", s_u, s_cat + off, s_dcat + off, s_c1, s_c2, s_sa, s_save, s_du, None, s_dc1, s_dc2, s_dsa, s_scr, B, 1024,
+                        6, 3, 2048, 0, 1, HF.ACT_RELU, 0.01, 3 | 4, s_st)
+                ch.call("mgvae_instance_norm_bwd", s_t2, s_g, s_b, s_stats, s_du, s_dt2, s_dg, s_db_, B, 1024, P, 1024, 0, HF.ACT_NONE, 0.0,
+                        s_scr + 4 * (3 * NP + NC), s_scr + 4 * (3 * NP + 2 * NC), s_save + 12 * NC, s_st)
+                # second transposed conv: weight gradient with the roles swapped, d/dx = the forward-conv kernel, which also applies
+                # relu'(t1) (the first transposed conv skipped its own activation-gradient pass)
+                if fl[1]:
+                    ch.call("mgvae_stream_fork", s_st, s_side)
+                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(B, 1024, 6, 3, 1024, h1, w1_, k2, k2, (0, 0), 1024, 1024)), s_dt2, s_t1,
+                            s_dw2, s_side)
+                m = ch.struct(nat.ActMask(0, 1024, 0, HF.ACT_RELU, 0.0), (("src", s_t1),))
+                ch.call("mgvae_conv2d_fwd_masked", ch.struct(_desc(B, 1024, 6, 3, 1024, h1, w1_, k2, k2, (0, 0), 1024, 1024)), s_dt2, s_w2, None,
+                        s_dt1, m, s_st)
+                if fl[0]:
+                    ch.call("mgvae_stream_fork", s_st, s_side)
+                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(B, co1, 1, 1, 2304, 1, 1, (1, 1), (1, 1), (0, 0), co1, 2304)), s_dt1, s_xbuf,
+                            s_dw1, s_side)
+                ch.call("mgvae_conv2d_fwd", ch.struct(_desc(B, co1, 1, 1, 2304, 1, 1, (1, 1), (1, 1), (0, 0), co1, 2304)), s_dt1, s_w1, None,
+                        dxs[si], s_st)
+            ch.call("mgvae_add_inplace", s_dx0, s_dx1, B * 2304, s_st)
+            n = B * 1152
+            lin_w = _desc(B, 2304, 1, 1, 1152, 1, 1, (1, 1), (1, 1), (0, 0), 2304, 1152)
+            for (col, s_g1, s_g2, s_mk, s_h, s_dpre, s_in, s_W, s_dW, s_dbias, s_dbuf, fw, fb) in (
+                    (0, s_gb, s_gb2, s_mk1, s_hb, s_dpre_b, s_bbuf, s_Wb, s_dWb, s_dbb, s_dbbuf, flags[3], flags[4]),
+                    (1152, s_gp, s_gp2, s_mk0, s_hp, s_dpre_p, s_pbuf, s_Wp, s_dWp, s_dbp, s_dpbuf, flags[1], flags[2])):
+                ch.call("mgvae_copy2d", s_g1, 1152, s_dx0 + 4 * col, 2304, 1152, B, s_st)
+                g = s_g1
+                if mode:
+                    ch.call("mgvae_mul", s_g1, s_mk, s_g2, n, s_st)
+                    g = s_g2
+                ch.call("mgvae_act_bwd", s_h, g, s_dpre, B, 1152, 1, 1152, 0, 1152, 0, 1152, 0, HF.ACT_RELU, 0.01, s_st)
+                if fw or fb:
+                    ch.call("mgvae_stream_fork", s_st, s_side)
+                if fw:
+                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(lin_w), s_in, s_dpre, s_dW, s_side)
+                if fb:
+                    ch.call("mgvae_channel_sum_accum", s_dpre, B, 1152, 1, 1152, 0, s_dbias, s_side)
+                ch.call("mgvae_conv2d_bwd_data", ch.struct(lin_w), s_dpre, s_W, None, s_dbuf, s_st)
+            if flags[0]:
+                ch.call("mgvae_embedding_bwd", s_pos, s_dpbuf + 4 * 1152, s_dtab, B, 1152, 332, 2304, s_st)
+            e = _chains[key] = (ch.finalize(), int(L.mgvae_cbam_bwd_scratch_floats(B, 1024, 6, 3)))
+        ch, nscr = e
+        dev = xbuf.device
+        if dy.dtype != dtype:
+            dy = dy.to(dtype)
+        if HF.cl_pitch(dy) != 2048:
+            dy = dy.contiguous(memory_format=HF.CL)
+        f = lambda *s_: torch.empty(s_, device=dev, dtype=torch.float32)
+        dcat, dx0, dx1 = f(B, 2048, 6, 3), f(B, 2304), f(B, 2304)
+        gb, gb2, dpre_b, dbbuf = f(B, 1152), (f(B, 1152) if mode else None), f(B, 1152), f(B, 2304)
+        gp, gp2, dpre_p, dpbuf = f(B, 1152), (f(B, 1152) if mode else None), f(B, 1152), f(B, 2304)
+        touched = [xbuf, bbuf, pbuf, dpre_b, dpre_p, dcat]
+        addr_st = []
+        tmp = []
+        for si in range(2):
+            w1, w2, g, b, c1, c2, sa = stems[7 * si:7 * si + 7]
+            t1, t2, u, stats, save = keep[5 * si:5 * si + 5]
+            co1, h1, w1_ = shapes[si]
+            du, dt2, dt1, scr = f(B, 1024, 6, 3), f(B, 1024, 6, 3), f(B, co1), f(nscr)
+            tmp += [du, dt2, dt1, scr]
+            touched += [t1, dt2, dt1]
+            addr_st += [w1.data_ptr(), w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(),
+                        t2.data_ptr(), u.data_ptr(), stats.data_ptr(), save.data_ptr(), du.data_ptr(), dt2.data_ptr(), dt1.data_ptr(), scr.data_ptr(),
+                        _ptr(_grad(w1)), _ptr(_grad(w2)), _ptr(_grad(g)), _ptr(_grad(b)), _ptr(_grad(c1)), _ptr(_grad(c2)), _ptr(_grad(sa))]
+        main, side = _side_for(B, any(flags), True, touched)
+        ch.run([position.data_ptr(), Wp.data_ptr(), Wb.data_ptr(), pbuf.data_ptr(), bbuf.data_ptr(), xbuf.data_ptr(), hp.data_ptr(), hb.data_ptr(),
+                _ptr(mk0), _ptr(mk1), cat.data_ptr(), dy.data_ptr(), dcat.data_ptr(), dx0.data_ptr(), dx1.data_ptr(), gb.data_ptr(), _ptr(gb2),
+                dpre_b.data_ptr(), dbbuf.data_ptr(), gp.data_ptr(), _ptr(gp2), dpre_p.data_ptr(), dpbuf.data_ptr(), _ptr(_grad(table)),
+                _ptr(_grad(Wp)), _ptr(_grad(bp)), _ptr(_grad(Wb)), _ptr(_grad(bb)), main, side] + addr_st)
+        dz = dbbuf[:, :1152] if need[0] else None
+        dpz = dbbuf[:, 1152:] if need[1] else None
+        dpf = dpbuf[:, :1152] if need[2] else None
+        return (dz, dpz, dpf) + (None,) * (15 + len(stems))
+
+
+def decoder_front(dec, z, pre_z, phrase_feature, position):
+    """``dec``: graph.decoder.Decoder"""
+    masks = dec._drop_masks
+    if masks is not None:
+        mode, m0, m1, seed, offs = 2, masks[0].contiguous(), masks[1].contiguous(), 0, (0, 0)
+    elif dec.training and dec.dropout_p > 0.0:
+        mode, m0, m1, seed = 1, None, None, HF._rng_state["seed"]
+        offs = (HF._next_offset(), HF._next_offset())          # phrase branch first, then the bar branch (graph/decoder.py:196,201)
+    else:
+        mode, m0, m1, seed, offs = 0, None, None, 0, (0, 0)
+    stems, geo = [], []
+    for stem in (dec.pitch, dec.time):                          # concat order: pitch -> channels 0..1023, time -> 1024..2047
+        a, b = getattr(stem, stem.first), getattr(stem, stem.second)
+        ca, sa = stem.cbam.channel_attention, stem.cbam.spatial_attention
+        stems += [a.weight, b.weight, stem.bn.weight, stem.bn.bias, ca.conv1.weight, ca.conv2.weight, sa.conv.weight]
+        geo.append((tuple(a.kernel_size), tuple(b.kernel_size)))
+    return _DecoderFrontFn.apply(z, pre_z, phrase_feature, position, mode, float(dec.dropout_p), seed, offs, HF.island_dtype(),
+                                 dec.pitch.bn.eps, tuple(geo), m0, m1, dec.position_embedding.weight, dec.phrase_linear.weight,
+                                 dec.phrase_linear.bias, dec.bar_linear.weight, dec.bar_linear.bias, *stems)
+
+
+def front_usable(z):
+    return ENABLED and z.is_cuda and z.dtype == torch.float32 and HF.get_nchw_operand_dtype() == "f32" and not HF.USE_DIRECT and HF.DEFER_ACT_GRAD

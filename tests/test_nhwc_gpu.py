@@ -375,6 +375,47 @@ def test_chained_ends_equal_the_per_op_path():
                         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), (name, sliced, frozen)
                     assert (float(res[True][2].abs().max()) == 0.0) == frozen
                     assert float(res[True][1].abs().max()) > 0
+        # the decoder's front (head + stems + layout change, hipops.blocks.decoder_front) inside the whole Decoder: Philox dropout
+        # (same seed and offsets -> same masks), injected masks, eval mode; the gradients of z, pre_z and the phrase feature
+        from graph.decoder import Decoder
+        for storage in ("f32", "bf16"):
+            HF.set_compute_dtype(storage)
+            for how in ("rng", "masks", "eval"):
+                res = {}
+                for run in ("per-op", "per-op again", "chained"):
+                    HB.ENABLED = run == "chained"
+                    torch.manual_seed(8)
+                    dec = Decoder([1024, 512, 256, 128, 64]).to(dev)
+                    with torch.no_grad():
+                        for prm in dec.parameters():
+                            if prm.dim() > 1:
+                                prm.copy_(torch.randn_like(prm) * (1.2 / (prm[0].numel() ** 0.5)))
+                    dec.train(how != "eval")
+                    gm = torch.Generator().manual_seed(4)
+                    dec._drop_masks = [((torch.rand(3, 1152, generator=gm) >= 0.3).float() / 0.7).to(dev) for _ in range(2)] if how == "masks" else None
+                    HF.manual_seed(77)
+                    opt = FlatParams(list(dec.parameters()))
+                    opt.zero_grad()
+                    gi = torch.Generator().manual_seed(5)
+                    zz = torch.randn(6, 1152, generator=gi).to(dev).requires_grad_(True)
+                    pf = torch.randn(3, 1152, generator=gi).to(dev).requires_grad_(True)
+                    pos = torch.tensor([3, 330, 17], device=dev)
+                    y = dec(zz[:3], zz[3:], pf, pos)
+                    y.backward(torch.linspace(-1, 1, y.numel(), device=dev).view_as(y))
+                    torch.cuda.synchronize()
+                    res[run] = (y.detach().clone(), zz.grad.clone(), pf.grad.clone(), opt.grad.clone())
+                # The per-op path against ITSELF gives the noise of this comparison: the stems' GEMMs split K with fp32 atomics, and
+                # the InstanceNorm backward over an 18-pixel map divides by standard deviations that random weights make small
+                # (measured 6e-4 of the largest entry on d(z, pre_z)).  The chained path must sit inside 4 x that noise (fp32) --
+                # a wrong call sequence is off by O(1); the step and agent tests hold the same path to the fp64 oracle.
+                for i, name in enumerate(("y", "d(z, pre_z)", "d(phrase feature)", "parameter gradients")):
+                    a, a2, b = res["per-op"][i], res["per-op again"][i], res["chained"][i]
+                    scale = float(a.abs().max())
+                    assert scale > 0, (storage, how, name)
+                    noise = float((a - a2).abs().max()) / scale
+                    tol = max(1e-5, 4 * noise) if storage == "f32" else max(3e-2, 4 * noise)
+                    assert noise < 2e-2 and float((a - b).abs().max()) <= tol * scale, (storage, how, name, float((a - b).abs().max()) / scale, noise)
+        HF.set_compute_dtype("f32")
         # the bar-pair discriminator (hipops/netchain.py): train / eval BatchNorm, trainable / frozen, gradient into the pair or not
         from graph.bar_discriminator import BarDiscriminator
         for training in (True, False):
