@@ -375,8 +375,12 @@ def test_chained_ends_equal_the_per_op_path():
                         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), (name, sliced, frozen)
                     assert (float(res[True][2].abs().max()) == 0.0) == frozen
                     assert float(res[True][1].abs().max()) > 0
-        # the decoder's front (head + stems + layout change, hipops.blocks.decoder_front) inside the whole Decoder: Philox dropout
-        # (same seed and offsets -> same masks), injected masks, eval mode; the gradients of z, pre_z and the phrase feature
+        # the decoder's front (head + stems + layout change, hipops.blocks.decoder_front) against the same three per-op calls of
+        # Decoder.forward: Philox dropout (same seed and offsets -> same masks), injected masks, eval mode; a fixed cotangent on the
+        # front's output, the gradients of z, pre_z, the phrase feature and the parameters.  (The comparison stops at the front's
+        # output on purpose: through the four up-sampling blocks with random weights the per-op path differs from ITSELF by 1e-2
+        # in fp32 and 30 % in bf16 storage from one run to the next -- tools/r3_front_noise.py -- which says nothing about the
+        # chain; the step and agent tests hold the whole decoder to the fp64 oracle with trained-scale weights.)
         from graph.decoder import Decoder
         for storage in ("f32", "bf16"):
             HF.set_compute_dtype(storage)
@@ -400,20 +404,27 @@ def test_chained_ends_equal_the_per_op_path():
                     zz = torch.randn(6, 1152, generator=gi).to(dev).requires_grad_(True)
                     pf = torch.randn(3, 1152, generator=gi).to(dev).requires_grad_(True)
                     pos = torch.tensor([3, 330, 17], device=dev)
-                    y = dec(zz[:3], zz[3:], pf, pos)
-                    y.backward(torch.linspace(-1, 1, y.numel(), device=dev).view_as(y))
+                    if run == "chained":
+                        assert HB.front_usable(zz[:3])
+                        o = HB.decoder_front(dec, zz[:3], zz[3:], pf, pos)
+                        assert "DecoderFront" in type(o.grad_fn).__name__
+                    else:
+                        o = HF.to_channels_last(dec.stems(dec.head(zz[:3], zz[3:], pf, pos)))
+                    assert tuple(o.shape) == (3, 2048, 6, 3) and o.dtype == (torch.bfloat16 if storage == "bf16" else torch.float32)
+                    ct = torch.linspace(-1, 1, o.numel(), device=dev).view(3, 6, 3, 2048).permute(0, 3, 1, 2).to(o.dtype)
+                    o.backward(ct)
                     torch.cuda.synchronize()
-                    res[run] = (y.detach().clone(), zz.grad.clone(), pf.grad.clone(), opt.grad.clone())
-                # The per-op path against ITSELF gives the noise of this comparison: the stems' GEMMs split K with fp32 atomics, and
-                # the InstanceNorm backward over an 18-pixel map divides by standard deviations that random weights make small
-                # (measured 6e-4 of the largest entry on d(z, pre_z)).  The chained path must sit inside 4 x that noise (fp32) --
-                # a wrong call sequence is off by O(1); the step and agent tests hold the same path to the fp64 oracle.
-                for i, name in enumerate(("y", "d(z, pre_z)", "d(phrase feature)", "parameter gradients")):
+                    res[run] = (o.detach().float().clone(), zz.grad.clone(), pf.grad.clone(), opt.grad.clone())
+                # The per-op path against ITSELF gives the noise of this comparison (the stems' GEMMs split K with fp32 atomics and
+                # the InstanceNorm backward over an 18-pixel map divides by standard deviations that random weights make small);
+                # the chained path must sit inside 4 x that noise -- a wrong call sequence is off by O(1).
+                for i, name in enumerate(("front", "d(z, pre_z)", "d(phrase feature)", "parameter gradients")):
                     a, a2, b = res["per-op"][i], res["per-op again"][i], res["chained"][i]
                     scale = float(a.abs().max())
                     assert scale > 0, (storage, how, name)
                     noise = float((a - a2).abs().max()) / scale
-                    tol = max(1e-5, 4 * noise) if storage == "f32" else max(3e-2, 4 * noise)
+                    floor = 8e-3 if (storage == "bf16" and i == 0) else 1e-5      # one bf16 ulp of the stored front
+                    tol = max(floor, 4 * noise)
                     assert noise < 2e-2 and float((a - b).abs().max()) <= tol * scale, (storage, how, name, float((a - b).abs().max()) / scale, noise)
         HF.set_compute_dtype("f32")
         # the bar-pair discriminator (hipops/netchain.py): train / eval BatchNorm, trainable / frozen, gradient into the pair or not
