@@ -268,6 +268,28 @@ int mgvae_layout_nhwc_to_nchw(const void* src, float* dst, int N, int C, int P, 
 int mgvae_mean_nhwc_fwd(const void* x, float* out, int N, int C, int P, int storage, void* stream);
 int mgvae_mean_nhwc_bwd(const float* dout, void* dx, int N, int C, int P, int storage, void* stream);
 
+/* The channels-last ENDS of the island (csrc/thin_nhwc.hip): the two convs with ONE channel on their other side, so the
+ * encoder trunks begin and the decoder ends without a layout change.
+ *  - conv2d_c1: a conv of a one-channel fp32 map x [N,1,H,W] into Cy in {16,32,64} channels, written channels-last
+ *    (`storage` type) with the descriptor's activation -- the encoder stems' first convs (reference
+ *    graph/encodingBlock.py:11-14,42-45: Conv2d(1, 32, (4,1)|(1,4), stride 2 on that axis, bias=False) + LeakyReLU).
+ *    d->Cx = d->x_ctot = 1, KH*KW <= 8; w is the reference's [Cy,1,KH,KW] fp32.  bwd_weight ACCUMULATES
+ *    dw[c][t] += sum g[pixel][c] x[tap t], g = dy, or dy * act'(ymask) when `ymask` (the forward's output) is given.
+ *  - conv2d_to1: a bias-free 1x1 conv of a channels-last map (rows = N*H*W pixel rows of C in {16..256} channels, a
+ *    channel slice allowed) into ONE fp32 channel with an activation -- the decoder's fit2 (graph/decoder.py:186,217:
+ *    Conv2d(64, 1, 1, bias=False) + Sigmoid).  bwd: g = dy * act'(y); dx[r,c] = g w[c] (`storage` type, may be NULL);
+ *    dw[c] += sum_r g x[r,c] (may be NULL).                                                                          */
+int mgvae_conv2d_c1_nhwc_fwd(const MgvaeConvDesc* d, const float* x, const float* w, void* y, int storage, void* stream);
+int mgvae_conv2d_c1_nhwc_bwd_weight(const MgvaeConvDesc* d, const float* x, const void* dy, const void* ymask, float* dw,
+                                    int storage, void* stream);
+int mgvae_conv2d_to1_nhwc_fwd(const void* x, const float* w, float* y, long rows, int C, int x_ctot, int x_coff, int act,
+                              float slope, int storage, void* stream);
+int mgvae_conv2d_to1_nhwc_bwd(const void* x, const float* w, const float* y, const float* dy, void* dx, float* dw, long rows,
+                              int C, int x_ctot, int x_coff, int act, float slope, int storage, void* stream);
+/* storage-type change of a dense tensor of n elements (n % 4 == 0), fp32 <-> bf16 (round to nearest even): the fp32 stems'
+ * concat entering a bf16 island and its gradient coming back (BASELINE.json configs 3-4)                            */
+int mgvae_cast_storage(const void* src, int src_storage, void* dst, int dst_storage, size_t n, void* stream);
+
 /* dx = dy * act'(y) given the activation OUTPUT y (ReLU/LeakyReLU/Sigmoid); all three
  * tensors may be channel slices of [N, ctot, P] buffers                               */
 int mgvae_act_bwd(const float* y, const float* dy, float* dx, int N, int C, int P,

@@ -120,7 +120,8 @@ class Decoder(nn.Module):
     def __init__(self, layers, channels_last=None):
         super().__init__()
         # fit1 and the four up-sampling blocks (94 % of the decoder's MACs) run on channels-last tensors, like the encoder
-        # trunks (graph/encoder.py); the Linear head, the two stems (1x1 maps: plain GEMMs) and fit2 (64 -> 1) stay NCHW
+        # trunks (graph/encoder.py), and so does fit2 (64 -> 1, hipops.functional.conv2d_to1_cl); the Linear head and the two
+        # stems (1x1 maps: plain GEMMs) stay NCHW
         cl = self.channels_last = (os.environ.get("MGVAE_LAYOUT", "nhwc") != "nchw") if channels_last is None else bool(channels_last)
         self.bar_linear = Linear(1152 * 2, 1152)
         self.phrase_linear = Linear(1152 * 2, 1152)
@@ -189,6 +190,6 @@ class Decoder(nn.Module):
         o = self.fit_stage(o)
         for blk in self.layers:
             o = blk(o)
-        if self.channels_last:
-            o = HF.to_nchw(o)
+        if self.channels_last:             # fit2 + Sigmoid read the channels-last map directly: no layout change at the exit
+            return HF.conv2d_to1_cl(o, self.fit2.weight, HF.ACT_SIGMOID)
         return self.fit2(o, act=HF.ACT_SIGMOID)

@@ -21,10 +21,11 @@ class _ConvTrunk(nn.Module):
         self.variational = bool(variational)
         # the residual / pooling trunk (78 % of the encoder's MACs) runs on channels-last tensors: K-contiguous conv
         # operands (csrc/conv_nhwc.inc) and the pixel-row InstanceNorm / CBAM kernels (csrc/norm_cbam_nhwc.inc).  The two
-        # stems (C = 1 inputs) stay NCHW; their concatenated output is converted once.  MGVAE_LAYOUT=nchw switches back.
+        # stems belong to the island too (round 3): their first conv reads the one-channel NCHW input and writes channels-last,
+        # so there is no layout change at the entry.  MGVAE_LAYOUT=nchw switches the whole trunk back.
         self.channels_last = (os.environ.get("MGVAE_LAYOUT", "nhwc") != "nchw") if channels_last is None else bool(channels_last)
-        self.time_pitch = TimePitchModule()
-        self.pitch_time = PitchTimeModule()
+        self.time_pitch = TimePitchModule(self.channels_last)
+        self.pitch_time = PitchTimeModule(self.channels_last)
         blocks = []
         for cin, cout in zip(layers[:-1], layers[1:]):
             blocks += [ResidualModule(cin, self.channels_last), PoolingModule(cin, cout, self.channels_last)]
@@ -38,22 +39,27 @@ class _ConvTrunk(nn.Module):
         self.last_kl = None
         self.apply(weights_init)
 
-    def stem_cat(self, x):
-        """the two stems side by side: [n, 1, h, w] -> [n, 64, h/2, w/2] (NCHW; graph/encoder.py:27-29)"""
+    def stem_cat(self, x, cast=True):
+        """the two stems side by side: [n, 1, h, w] -> [n, 64, h/2, w/2] (graph/encoder.py:27-29), in the island's layout
+        (``cast=False``: left in the stems' own fp32 storage -- tests)"""
         n, _, h, w = x.shape
-        cat = torch.empty((n, 64, h // 2, w // 2), device=x.device, dtype=torch.float32)
+        if self.channels_last:
+            # the stems stay fp32 storage (their 32-channel conv is below the bf16 kernels' 64-channel K tile); a bf16 island
+            # begins with one cast of the concat -- the pass the layout change used to be
+            cat = HF.new_channels_last(n, 64, h // 2, w // 2, x.device, torch.float32)
+        else:
+            cat = torch.empty((n, 64, h // 2, w // 2), device=x.device, dtype=torch.float32)
         pitch = self.pitch_time(x, out=cat[:, :32])
         time = self.time_pitch(x, out=cat[:, 32:])
-        return HF.join(cat, pitch, time)
+        o = HF.join(cat, pitch, time)
+        return HF.cast_cl(o, HF.island_dtype()) if (self.channels_last and cast) else o
 
     def features(self, x):
         """the conv trunk up to the pooled [n, 1024] features (everything but the final Linear)"""
         if self.channels_last and HB.entry_usable(x):
-            o = HB.trunk_entry(x, self)            # both stems + the layout change: one node, one launch chain
+            o = HB.trunk_entry(x, self)            # both stems: one node, one launch chain
         else:
             o = self.stem_cat(x)
-            if self.channels_last:
-                o = HF.to_channels_last(o)
         # when the gradient of this tensor exists, every parameter gradient of ``layers`` and ``linear`` is enqueued:
         # the data-parallel step hooks it to start that range's all-reduce early (hipops/train.py)
         self.trunk_input = o if o.requires_grad else None

@@ -13,13 +13,16 @@ from graph.weights_initializer import weights_init
 
 
 class _Stem(nn.Module):
-    """two thin 1-D convs; subclasses fix which axis goes first"""
+    """two thin 1-D convs; subclasses fix which axis goes first.  ``channels_last=True``: the stem belongs to the island --
+    its first conv (one input channel) writes channels-last directly (hipops.functional.conv2d_c1_cl), the 32 -> 32 conv runs on
+    the island's matrix kernels with its weight stored [Cout, KH, KW, Cin], InstanceNorm / CBAM are the channels-last kernels."""
     first, second = "time", "pitch"
 
-    def __init__(self):
+    def __init__(self, channels_last=False):
         super().__init__()
-        convs = {"time": lambda cin: Conv2d(cin, 32, (4, 1), stride=(2, 1), padding=(1, 0), bias=False),
-                 "pitch": lambda cin: Conv2d(cin, 32, (1, 4), stride=(1, 2), padding=(0, 1), bias=False)}
+        cl = self.channels_last = bool(channels_last)
+        convs = {"time": lambda cin: Conv2d(cin, 32, (4, 1), stride=(2, 1), padding=(1, 0), bias=False, channels_last=cl and cin != 1),
+                 "pitch": lambda cin: Conv2d(cin, 32, (1, 4), stride=(1, 2), padding=(0, 1), bias=False, channels_last=cl and cin != 1)}
         setattr(self, self.first, convs[self.first](1))
         setattr(self, self.second, convs[self.second](32))
         self.bn = InstanceNorm2d(32, eps=1e-5, momentum=0.01, affine=True)
@@ -27,10 +30,16 @@ class _Stem(nn.Module):
         self.apply(weights_init)
 
     def forward(self, x, out=None):
+        c1, c2 = getattr(self, self.first), getattr(self, self.second)
+        if self.channels_last:
+            # the LeakyReLU gradient of the first conv is applied by the second conv's data gradient (its only consumer)
+            o = HF.conv2d_c1_cl(x, c1.weight, c1.stride, c1.padding, HF.ACT_LEAKY, 0.01, defer_act_grad=True)
+            o = c2(o, in_act=(HF.ACT_LEAKY, 0.01))
+            return self.cbam.fused_norm(o, self.bn, 1, act=HF.ACT_LEAKY, slope=0.01, out=out, channels_last=True)
         # (no deferred activation gradient here: the second conv's stride-2 data gradient stores every other pixel, and
         # the masked epilogue costs it more -- 190 vs 106 us -- than the separate LeakyReLU-gradient pass it would save)
-        o = getattr(self, self.first)(x, act=HF.ACT_LEAKY, slope=0.01)
-        o = getattr(self, self.second)(o)
+        o = c1(x, act=HF.ACT_LEAKY, slope=0.01)
+        o = c2(o)
         return self.cbam.fused_norm(o, self.bn, 1, act=HF.ACT_LEAKY, slope=0.01, out=out)
 
 

@@ -92,6 +92,11 @@ SIGNATURES = {
     "mgvae_layout_nhwc_to_nchw": (c_int, [P, P] + [c_int] * 8 + [P]),
     "mgvae_mean_nhwc_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "mgvae_mean_nhwc_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "mgvae_conv2d_c1_nhwc_fwd": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, c_int, P]),
+    "mgvae_conv2d_c1_nhwc_bwd_weight": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, c_int, P]),
+    "mgvae_conv2d_to1_nhwc_fwd": (c_int, [P, P, P, ctypes.c_long, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    "mgvae_conv2d_to1_nhwc_bwd": (c_int, [P, P, P, P, P, P, ctypes.c_long, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    "mgvae_cast_storage": (c_int, [P, c_int, P, c_int, c_size_t, P]),
     "mgvae_act_bwd": (c_int, [P, P, P] + [c_int] * 10 + [c_float, P]),
     "mgvae_copy2d": (c_int, [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P]),
     "mgvae_add_inplace": (c_int, [P, P, c_size_t, P]),

@@ -589,8 +589,10 @@ def mlp_usable(x):
 
 class _TrunkEntryFn(torch.autograd.Function):
     """Both stems of an encoder trunk (graph/encodingBlock.py:25-36,56-67: thin conv -> LeakyReLU -> thin conv -> InstanceNorm ->
-    +CBAM -> LeakyReLU, each writing its half of the concat of graph/encoder.py:27-29) and the layout change into the
-    channels-last island, as one node: [N,1,H,W] fp32 -> channels-last [N,64,H/2,W/2] of the island's storage type."""
+    +CBAM -> LeakyReLU, each writing its half of the concat of graph/encoder.py:27-29) as one node, inside the island:
+    [N,1,H,W] fp32 -> channels-last [N,64,H/2,W/2] of the island's storage type.  The one-channel conv writes channels-last
+    itself (mgvae_conv2d_c1_nhwc_fwd), the 32 -> 32 conv is the island's matrix kernel, InstanceNorm / CBAM the channels-last
+    ones; the stems compute in fp32 storage (a bf16 island begins with one cast of the concat)."""
 
     @staticmethod
     def forward(ctx, x, eps, geo, dtype, *prm):
@@ -598,117 +600,110 @@ class _TrunkEntryFn(torch.autograd.Function):
         x = x.contiguous()
         N, _, H, W = x.shape
         OH, OW = H // 2, W // 2
-        P, NC = OH * OW, N * 32
-        st = HF.STORE_BF16 if dtype == torch.bfloat16 else HF.STORE_F32
-        key = ("entry-f", N, H, W, geo, st, float(eps))
+        eng = "x3" if HF.FP32_ENGINE == "x3" else "f32"
+        key = ("entry-f", N, H, W, geo, dtype, eng, float(eps))
         e = _chains.get(key)
         L = nat.lib()
         if e is None:
             ch = Chain()
-            s_x, s_cat, s_ycl, s_st = ch.slots(4)
+            s_x, s_cat, s_ycl, s_ws, s_st = ch.slots(5)
+            em = _Emit(ch, eng, s_ws, s_st)
             stems = []
             for si in range(2):
                 (k1, s1, p1), (k2, s2, p2) = geo[si]
                 H1, W1 = (H + 2 * p1[0] - k1[0]) // s1[0] + 1, (W + 2 * p1[1] - k1[1]) // s1[1] + 1
                 if ((H1 + 2 * p2[0] - k2[0]) // s2[0] + 1, (W1 + 2 * p2[1] - k2[1]) // s2[1] + 1) != (OH, OW):
                     raise RuntimeError("trunk entry: a stem does not halve the map")
-                s_w1, s_w2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_u, s_stats, s_save = ch.slots(12)
+                s_w1, s_wk2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_save = ch.slots(10)
                 stems.append((H1, W1))
-                ch.call("mgvae_conv2d_fwd", ch.struct(_desc(N, 1, H, W, 32, H1, W1, k1, s1, p1, 1, 32, HF.ACT_LEAKY, 0.01)), s_x, s_w1, None,
-                        s_t1, s_st)
-                ch.call("mgvae_conv2d_fwd", ch.struct(_desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)), s_t1, s_w2, None, s_t2, s_st)
-                ch.call("mgvae_instance_norm_fwd", s_t2, s_g, s_b, s_u, s_stats, N, 32, P, 32, 0, eps, HF.ACT_NONE, 0.0, s_save + 4 * NC,
-                        s_save + 8 * NC, s_save + 12 * NC, s_st)
-                ch.call("mgvae_cbam_fwd", s_u, None, s_c1, s_c2, s_sa, s_cat + 4 * si * 32 * P, s_save, N, 32, OH, OW, 64, 0, 1, HF.ACT_LEAKY,
-                        0.01, 3 | 4, s_st)
-            ch.call("mgvae_layout_nchw_to_nhwc", s_cat, s_ycl, N, 64, P, 64, 0, 64, 0, st, s_st)
-            e = _chains[key] = (ch.finalize(), stems, int(L.mgvae_cbam_save_floats(N, 32, OH, OW)))
-        ch, stems, nsave = e
+                ch.call("mgvae_conv2d_c1_nhwc_fwd", ch.struct(_desc(N, 1, H, W, 32, H1, W1, k1, s1, p1, 1, 32, HF.ACT_LEAKY, 0.01)), s_x, s_w1,
+                        s_t1, HF.STORE_F32, s_st)
+                em.fwd(_desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32), s_t1, s_wk2, None, s_t2)
+                ch.call("mgvae_norm_cbam_nhwc_fwd", s_t2, s_g, s_b, None, 0, 0, s_c1, s_c2, s_sa, s_cat, s_save, N, 32, OH, OW, 64, 32 * si,
+                        eps, 1, HF.ACT_LEAKY, 0.01, HF.STORE_F32, s_st)
+            if dtype == torch.bfloat16:
+                ch.call("mgvae_cast_storage", s_cat, HF.STORE_F32, s_ycl, HF.STORE_BF16, N * 64 * OH * OW, s_st)
+            e = _chains[key] = (ch.finalize(), stems, em.ws_bytes, int(L.mgvae_norm_cbam_nhwc_save_floats(N, 32, OH, OW)))
+        ch, stems, wsn, nsave = e
         dev = x.device
-        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-        cat = f(N, 64, OH, OW)
-        ycl = HF.new_channels_last(N, 64, OH, OW, dev, dtype)
-        addr = [x.data_ptr(), cat.data_ptr(), ycl.data_ptr(), _main()]
+        cat = HF.new_channels_last(N, 64, OH, OW, dev, torch.float32)
+        ycl = HF.new_channels_last(N, 64, OH, OW, dev, dtype) if dtype == torch.bfloat16 else cat
+        ws = torch.empty(wsn, device=dev, dtype=torch.uint8) if wsn else None
+        addr = [x.data_ptr(), cat.data_ptr(), ycl.data_ptr(), _ptr(ws), _main()]
         keep = []
         for si in range(2):
             w1, w2, g, b, c1, c2, sa = prm[7 * si:7 * si + 7]
+            HF._cl_weight(w2, "trunk entry")
             H1, W1 = stems[si]
-            t1, t2, u, stats, save = f(N, 32, H1, W1), f(N, 32, OH, OW), f(N, 32, OH, OW), f(2 * NC), f(nsave)
-            keep += [t1, t2, u, stats, save]
-            addr += [w1.data_ptr(), w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(),
-                     t2.data_ptr(), u.data_ptr(), stats.data_ptr(), save.data_ptr()]
-        ch.run(addr)              # slot order: the four shared slots first, then 12 per stem
+            wk2, _ = _weights(eng, w2)
+            t1, t2, save = HF.new_channels_last(N, 32, H1, W1, dev, torch.float32), HF.new_channels_last(N, 32, OH, OW, dev, torch.float32), _f32(nsave, dev)
+            keep += [t1, t2, save]
+            addr += [w1.data_ptr(), wk2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(),
+                     t2.data_ptr(), save.data_ptr()]
+        ch.run(addr)              # slot order: the five shared slots first, then 10 per stem
         ctx.save_for_backward(x, cat, *prm, *keep)
-        ctx.cfg = (float(eps), geo, st, stems, dtype)
+        ctx.cfg = (float(eps), geo, stems, dtype, eng)
         return ycl
 
     @staticmethod
     def backward(ctx, dy):
-        eps, geo, st, stems, dtype = ctx.cfg
+        eps, geo, stems, dtype, eng = ctx.cfg
         sv = ctx.saved_tensors
         x, cat, prm, keep = sv[0], sv[1], sv[2:16], sv[16:]
         N, _, H, W = x.shape
         OH, OW = H // 2, W // 2
-        P, NC, NP = OH * OW, N * 32, N * OH * OW
         flags = tuple(bool(p.requires_grad) for p in prm)
-        tw = bool(HF.USE_TRANSPOSED_W)
-        key = ("entry-b", N, H, W, geo, st, flags, tw)
+        key = ("entry-b", N, H, W, geo, dtype, eng, flags)
         e = _chains.get(key)
         L = nat.lib()
         if e is None:
             ch = Chain()
-            s_x, s_cat, s_dy, s_dcat, s_st, s_side = ch.slots(6)
-            ch.call("mgvae_layout_nhwc_to_nchw", s_dy, s_dcat, N, 64, P, 64, 0, 64, 0, st, s_st)
+            s_x, s_cat, s_dy, s_dcat, s_ws, s_st, s_side = ch.slots(7)
+            em = _Emit(ch, eng, s_ws, s_st)
+            if dtype == torch.bfloat16:
+                ch.call("mgvae_cast_storage", s_dy, HF.STORE_BF16, s_dcat, HF.STORE_F32, N * 64 * OH * OW, s_st)
             for si in range(2):
                 (k1, s1, p1), (k2, s2, p2) = geo[si]
                 H1, W1 = stems[si]
                 fl = flags[7 * si:7 * si + 7]
-                (s_w2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_u, s_stats, s_save, s_du, s_dt2, s_dt1, s_dt1a, s_wt, s_scr, s_dw1, s_dw2, s_dg,
-                 s_db, s_dc1, s_dc2, s_dsa) = ch.slots(24)
-                off = 4 * si * 32 * P
-                ch.call("mgvae_cbam_bwd", s_u, s_cat + off, s_dcat + off, s_c1, s_c2, s_sa, s_save, s_du, None, s_dc1, s_dc2, s_dsa, s_scr,
-                        N, 32, OH, OW, 64, 0, 1, HF.ACT_LEAKY, 0.01, 3 | 4, s_st)
-                ch.call("mgvae_instance_norm_bwd", s_t2, s_g, s_b, s_stats, s_du, s_dt2, s_dg, s_db, N, 32, P, 32, 0, HF.ACT_NONE, 0.0,
-                        s_scr + 4 * (3 * NP + NC), s_scr + 4 * (3 * NP + 2 * NC), s_save + 12 * NC, s_st)
+                (s_wt2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_save, s_dt2, s_dt1, s_scr, s_dw1, s_dw2, s_dg, s_db, s_dc1, s_dc2,
+                 s_dsa) = ch.slots(19)
+                ch.call("mgvae_norm_cbam_nhwc_bwd", s_t2, s_g, s_b, s_cat, s_dcat, s_c1, s_c2, s_sa, s_save, s_dt2, None, s_dg, s_db, s_dc1,
+                        s_dc2, s_dsa, s_scr, N, 32, OH, OW, 64, 32 * si, 1, HF.ACT_LEAKY, 0.01, HF.STORE_F32, s_st)
+                d2 = _desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)
                 if fl[1]:
                     ch.call("mgvae_stream_fork", s_st, s_side)
-                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)), s_t1, s_dt2, s_dw2, s_side)
-                d2 = _desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)
-                if tw and k2[0] * k2[1] > 1:
-                    ch.call("mgvae_weight_transpose", s_w2, s_wt, 32, 32, k2[0] * k2[1], s_st)
-                    ch.call("mgvae_conv2d_bwd_data_tw", ch.struct(d2), s_dt2, s_wt, None, s_dt1, s_st)
-                else:
-                    ch.call("mgvae_conv2d_bwd_data", ch.struct(d2), s_dt2, s_w2, None, s_dt1, s_st)
+                    em.bwd_weight(d2, s_t1, s_dt2, s_dw2, s_side)
                 if fl[0]:
-                    ch.call("mgvae_act_bwd", s_t1, s_dt1, s_dt1a, N, 32, H1 * W1, 32, 0, 32, 0, 32, 0, HF.ACT_LEAKY, 0.01, s_st)
+                    # the data gradient of the second conv applies the first conv's LeakyReLU' while it stores; it only feeds dw1
+                    em.bwd_data(d2, s_dt2, s_wt2, None, s_dt1, em.mask(s_t1, 32, HF.ACT_LEAKY, 0.01))
                     ch.call("mgvae_stream_fork", s_st, s_side)
-                    ch.call("mgvae_conv2d_bwd_weight", ch.struct(_desc(N, 1, H, W, 32, H1, W1, k1, s1, p1, 1, 32)), s_x, s_dt1a, s_dw1, s_side)
-            e = _chains[key] = (ch.finalize(), int(L.mgvae_cbam_bwd_scratch_floats(N, 32, OH, OW)))
-        ch, nscr = e
+                    ch.call("mgvae_conv2d_c1_nhwc_bwd_weight", ch.struct(_desc(N, 1, H, W, 32, H1, W1, k1, s1, p1, 1, 32, HF.ACT_LEAKY, 0.01)), s_x,
+                            s_dt1, None, s_dw1, HF.STORE_F32, s_side)
+            e = _chains[key] = (ch.finalize(), em.ws_bytes, int(L.mgvae_norm_cbam_nhwc_scratch_floats(N, 32, OH, OW)))
+        ch, wsn, nscr = e
         dev = x.device
         if dy.dtype != dtype:
             dy = dy.to(dtype)
         if HF.cl_pitch(dy) != 64:
             dy = dy.contiguous(memory_format=HF.CL)
-        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
-        dcat = f(N, 64, OH, OW)
+        dcat = HF.new_channels_last(N, 64, OH, OW, dev, torch.float32) if dtype == torch.bfloat16 else dy
+        ws = torch.empty(wsn, device=dev, dtype=torch.uint8) if wsn else None
         touched = [x, dcat]
-        main_side = None
-        addr_stems = []
-        tmp = []
+        addr_stems, tmp = [], []
         for si in range(2):
             w1, w2, g, b, c1, c2, sa = prm[7 * si:7 * si + 7]
-            t1, t2, u, stats, save = keep[5 * si:5 * si + 5]
+            t1, t2, save = keep[3 * si:3 * si + 3]
             H1, W1 = stems[si]
-            du, dt2, dt1, dt1a, wt, scr = f(N, 32, OH, OW), f(N, 32, OH, OW), f(N, 32, H1, W1), f(N, 32, H1, W1), f(w2.numel()), f(nscr)
-            tmp += [du, dt2, dt1, dt1a, wt, scr]
-            touched += [t1, dt2, dt1a]
-            addr_stems += [w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(), t2.data_ptr(),
-                           u.data_ptr(), stats.data_ptr(), save.data_ptr(), du.data_ptr(), dt2.data_ptr(), dt1.data_ptr(), dt1a.data_ptr(),
-                           wt.data_ptr(), scr.data_ptr(), _ptr(_grad(w1)), _ptr(_grad(w2)), _ptr(_grad(g)), _ptr(_grad(b)), _ptr(_grad(c1)),
-                           _ptr(_grad(c2)), _ptr(_grad(sa))]
+            _, wt2 = _weights(eng, w2)
+            dt2, dt1, scr = HF.new_channels_last(N, 32, OH, OW, dev, torch.float32), HF.new_channels_last(N, 32, H1, W1, dev, torch.float32), _f32(nscr, dev)
+            tmp += [dt2, dt1, scr]
+            touched += [t1, dt2, dt1]
+            addr_stems += [wt2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(), t2.data_ptr(),
+                           save.data_ptr(), dt2.data_ptr(), dt1.data_ptr(), scr.data_ptr(), _ptr(_grad(w1)), _ptr(_grad(w2)), _ptr(_grad(g)),
+                           _ptr(_grad(b)), _ptr(_grad(c1)), _ptr(_grad(c2)), _ptr(_grad(sa))]
         main, side = _side_for(N, any(flags), True, touched)
-        ch.run([x.data_ptr(), cat.data_ptr(), dy.data_ptr(), dcat.data_ptr(), main, side] + addr_stems)
+        ch.run([x.data_ptr(), cat.data_ptr(), dy.data_ptr(), dcat.data_ptr(), _ptr(ws), main, side] + addr_stems)
         return (None,) * (4 + 14)
 
 

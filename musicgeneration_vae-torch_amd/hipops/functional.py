@@ -1466,6 +1466,123 @@ def conv2d_cl(x, w, b=None, stride=(1, 1), pad=(0, 0), act=ACT_NONE, slope=0.01,
     return _ConvClFn.apply(x, w, b, stride, pad, act, slope, out, in_act, defer_act_grad)
 
 
+class _CastClFn(torch.autograd.Function):
+    """a dense channels-last tensor in the other storage type (fp32 <-> bf16); the gradient comes back in the input's type"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ct = _need_cl(x, "cast_cl")
+        N, C, H, W = x.shape
+        if ct != C:
+            raise RuntimeError("cast_cl: dense tensors only")
+        ctx.src = x.dtype
+        y = new_channels_last(N, C, H, W, x.device, dtype)
+        nat.check(nat.lib().mgvae_cast_storage(_p(x), _store(x), _p(y), _store(y), x.numel(), _s()), "cast_storage")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = dy.shape
+        if cl_pitch(dy) != C:
+            dy = dy.contiguous(memory_format=CL)
+        dx = new_channels_last(N, C, H, W, dy.device, ctx.src)
+        nat.check(nat.lib().mgvae_cast_storage(_p(dy), _store(dy), _p(dx), _store(dx), dy.numel(), _s()), "cast_storage")
+        return dx, None
+
+
+def cast_cl(x, dtype):
+    return x if x.dtype == dtype else _CastClFn.apply(x, dtype)
+
+
+class _ConvC1ClFn(torch.autograd.Function):
+    """A conv of a ONE-channel NCHW fp32 map into a channels-last tensor of the island's storage type, activation fused
+    (csrc/thin_nhwc.hip) -- the encoder stems' first convs (graph/encodingBlock.py:11-14,42-45).  The input carries no
+    gradient (it is data); with ``defer_act_grad`` the consumer's data gradient has already applied act'(y), otherwise the
+    weight-gradient kernel multiplies it in while it reads dy."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, act, slope, dtype, defer_act_grad):
+        _need_cuda(x, "conv2d_c1_cl")
+        if x.requires_grad:
+            raise RuntimeError("conv2d_c1_cl: the one-channel input is data (no gradient path)")
+        x = x.contiguous()
+        N, Cx, H, W = x.shape
+        Cy, _, KH, KW = w.shape
+        if Cx != 1 or x.dtype != torch.float32:
+            raise RuntimeError("conv2d_c1_cl: expected an fp32 [N,1,H,W] input, got %s %s" % (tuple(x.shape), x.dtype))
+        OH = (H + 2 * pad[0] - KH) // stride[0] + 1
+        OW = (W + 2 * pad[1] - KW) // stride[1] + 1
+        y = new_channels_last(N, Cy, OH, OW, x.device, dtype)
+        wc = w if w.is_contiguous() else w.contiguous()
+        d = _desc(N, 1, H, W, Cy, OH, OW, (KH, KW), stride, pad, 1, Cy, act, slope)
+        nat.check(nat.lib().mgvae_conv2d_c1_nhwc_fwd(ctypes.byref(d), _p(x), _p(wc), _p(y), _store(y), _s()), "conv2d_c1_nhwc_fwd")
+        defer = bool(defer_act_grad) and DEFER_ACT_GRAD
+        ctx.geom = (N, H, W, Cy, OH, OW, (KH, KW), stride, pad, act, slope, defer)
+        ctx.save_for_backward(x, w, y if (act != ACT_NONE and not defer) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, H, W, Cy, OH, OW, k, s, p, act, slope, defer = ctx.geom
+        if w.requires_grad:
+            if _trunk_streams or _used_sides:
+                _ensure_join_callback()
+            like = y if y is not None else dy
+            dy = _as_cl(dy, like)
+            if _need_cl(dy, "conv2d_c1_cl backward") != Cy:
+                dy = dy.contiguous(memory_format=CL)
+            if not w.is_contiguous():
+                raise RuntimeError("conv2d_c1_cl: the weight gradient is accumulated in the reference's [Cy,1,KH,KW] layout")
+            d = _desc(N, 1, H, W, Cy, OH, OW, k, s, p, 1, Cy, act, slope)
+            nat.check(nat.lib().mgvae_conv2d_c1_nhwc_bwd_weight(ctypes.byref(d), _p(x), _p(dy), _p(y) if y is not None else None,
+                                                              _p(grad_slot(w)), _store(dy), _s()), "conv2d_c1_nhwc_bwd_weight")
+        return None, None, None, None, None, None, None, None
+
+
+def conv2d_c1_cl(x, w, stride, pad, act=ACT_NONE, slope=0.01, dtype=None, defer_act_grad=False):
+    return _ConvC1ClFn.apply(x, w, tuple(stride), tuple(pad), act, slope, dtype if dtype is not None else torch.float32, defer_act_grad)
+
+
+class _ConvTo1ClFn(torch.autograd.Function):
+    """A bias-free 1x1 conv of a channels-last tensor into ONE fp32 channel with its activation (csrc/thin_nhwc.hip) -- the
+    decoder's fit2 + Sigmoid (graph/decoder.py:186,217): [N,C,H,W] channels-last -> [N,1,H,W] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, act, slope):
+        xct = _need_cl(x, "conv2d_to1_cl")
+        N, C, H, W = x.shape
+        if tuple(w.shape) != (1, C, 1, 1):
+            raise RuntimeError("conv2d_to1_cl: weight %s does not map %d channels to one" % (tuple(w.shape), C))
+        y = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+        nat.check(nat.lib().mgvae_conv2d_to1_nhwc_fwd(_p(x), _p(w), _p(y), N * H * W, C, xct, 0, act, slope, _store(x), _s()), "conv2d_to1_nhwc_fwd")
+        ctx.cfg = (act, slope, xct)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, slope, xct = ctx.cfg
+        N, C, H, W = x.shape
+        if _trunk_streams or _used_sides:
+            _ensure_join_callback()
+        dy = dy.contiguous()
+        need_dx, need_dw = ctx.needs_input_grad[0], w.requires_grad
+        dx = new_channels_last(N, C, H, W, x.device, x.dtype) if need_dx else None
+        if need_dx or need_dw:
+            if need_dx and xct != C:
+                raise RuntimeError("conv2d_to1_cl: the input gradient is written dense")
+            nat.check(nat.lib().mgvae_conv2d_to1_nhwc_bwd(_p(x), _p(w), _p(y), _p(dy), _p(dx) if need_dx else None,
+                                                        _p(grad_slot(w)) if need_dw else None, N * H * W, C, xct, 0, act, slope, _store(x), _s()),
+                      "conv2d_to1_nhwc_bwd")
+        return dx, None, None, None
+
+
+def conv2d_to1_cl(x, w, act=ACT_NONE, slope=0.01):
+    return _ConvTo1ClFn.apply(x, w, act, slope)
+
+
 class _NormCbamClFn(torch.autograd.Function):
     """InstanceNorm2d -> CBAM -> (+residual) -> activation on channels-last tensors as ONE node
     (graph/encodingBlock.py:48-55,93-100,110-126): csrc/norm_cbam_nhwc.inc"""

@@ -149,12 +149,33 @@ def main():
         tol = 2e-2 if args.transport != "bf16" else 3e-2       # bf16 wire: 2^-9 per addend and per sum
         loose = 0.3 if args.transport == "bf16" else 0.0
         if args.dtype == "bf16":
-            # bf16 storage: the two-rank run sees 2-bar shards (other tiles / tuner choices than the 4-bar reference step),
-            # and a 4-bar bf16 step is chaotic at bf16 resolution: direction and size must agree
+            # bf16 storage: a 4-bar bf16 step is chaotic at bf16 resolution and sees other tiles than the
+            # 2-bar shards, so the full-batch reference above only has to agree in direction and size.  The tight check is
+            # against the SAME per-shard launches on one rank: one fresh step per shard from the same initial weights, gradients
+            # averaged (tests/test_dp_gpu.py pins the tuner off, so every process launches the same tiles).  That reference is
+            # computed twice; its own run-to-run distance (fp32 atomics outside the island flipping bf16 roundings) is the noise
+            # floor of the comparison.
             cos = float((g_dp * g_ref).sum() / (g_dp.norm() * g_ref.norm()))
-            print("DPCHECK bf16 cosine=%.4f" % cos)
+            print("DPCHECK bf16 cosine=%.4f (full-batch reference: l2_rel=%.3e)" % (cos, l2))
+            micro = []
+            for rep in range(2):
+                acc = torch.zeros_like(g_dp)
+                for r in range(world):
+                    one = build(dev, 1, args.variational)
+                    assert torch.equal(one.opt.flat, w0)
+                    if args.variational:
+                        one.gen.eval()
+                    one(*(t[r::world].contiguous().to(dev) for t in batch))
+                    torch.cuda.synchronize()
+                    acc += one.opt.grad
+                    del one
+                micro.append(acc / world)
+            den2 = micro[0].norm().item()
+            noise = (micro[0] - micro[1]).norm().item() / den2
+            l2m = min((g_dp - m).norm().item() for m in micro) / den2
+            print("DPCHECK bf16 micro-step reference: l2_rel=%.3e own_noise=%.3e" % (l2m, noise))
+            ok = cos > 0.8 and l2m <= max(1e-2, 3.0 * noise)
             tol, loose = 0.6, 1.0
-            ok = cos > 0.8
         ok = ok and same and l2 < tol and frac < 2e-2 + loose and moved > 0
         ok = ok and n_streams <= 2                             # phrase trunk + ONE weight-gradient stream
         # early buckets: the decoder's always; the bar-encoder trunk's only when both passes ran stacked

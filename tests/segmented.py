@@ -107,7 +107,7 @@ def segmented_generator_check(gen, opt, gsd, bound, grads, position, masks, enc_
                 self.pitch_time, self.time_pitch = t.pitch_time, t.time_pitch
         cat_ref = torch.cat((bound[p + "pitch_time"], bound[p + "time_pitch"]), dim=1)
         cat_grad = torch.cat((grads[p + "pitch_time"], grads[p + "time_pitch"]), dim=1)
-        seg(p + "stems", Stems(trunk), trunk.stem_cat,
+        seg(p + "stems", Stems(trunk), lambda x, trunk=trunk: trunk.stem_cat(x, cast=False),
             lambda sd, x: torch.cat((R.enc_pitch_time(sd, "pitch_time.", x), R.enc_time_pitch(sd, "time_pitch.", x)), dim=1),
             p, [x_in], [None], cat_grad, cat_ref)
         prev, prev_g = cat_ref, cat_grad
@@ -163,8 +163,9 @@ def segmented_generator_check(gen, opt, gsd, bound, grads, position, masks, enc_
         seg(p + "layers.%d" % i, blk, wrap(blk), lambda sd, x, ofn=ofn: ofn(sd, "", x), p + "layers.%d." % i, [prev], [prev_g], out_g, out_ref,
             island=True)
         prev, prev_g = out_ref, out_g
-    seg(p + "fit2", dec.fit2, lambda x: dec.fit2(x, act=HF.ACT_SIGMOID), lambda sd, x: torch.sigmoid(F.conv2d(x, sd["weight"])),
-        p + "fit2.", [prev], [prev_g], grads["gen"], bound["gen"])
+    seg(p + "fit2", dec.fit2, (lambda x: HF.conv2d_to1_cl(cl(x), dec.fit2.weight, HF.ACT_SIGMOID)) if dec.channels_last else (lambda x: dec.fit2(x, act=HF.ACT_SIGMOID)),
+        lambda sd, x: torch.sigmoid(F.conv2d(x, sd["weight"])),
+        p + "fit2.", [prev], [prev_g], grads["gen"], bound["gen"], island=dec.channels_last)      # reads (bf16 mode: bf16) island storage
     opt.zero_grad()
     rules = {k: v for k, v in report.items() if ":dx" not in k}
     n_strict = sum(1 for v in rules.values() if v == "strict")

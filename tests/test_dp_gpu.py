@@ -45,10 +45,11 @@ def test_two_rank_step_bf16_gradient_transport():
 
 def test_two_rank_step_bf16_storage():
     """BASELINE.json configs[2]'s shape of run (bf16 storage inside the island + data parallel) at two ranks: identical
-    weights on both ranks, stream budget, early buckets, and the all-reduced gradient agrees with the single-process bf16
-    step in direction and size"""
-    out = _run(29616, "--dtype", "bf16")
-    assert "DPCHECK bf16 cosine" in out
+    weights on both ranks, stream budget, early buckets; the all-reduced gradient equals (1e-2 or 3x the reference's own
+    run-to-run noise) the average of the two shards' single-process steps -- same launches: the tuner is pinned off -- and
+    agrees with the single-process 4-bar bf16 step in direction and size"""
+    out = _run(29616, "--dtype", "bf16", env_extra={"MGVAE_AUTOTUNE": "0"})
+    assert "DPCHECK bf16 cosine" in out and "DPCHECK bf16 micro-step reference" in out
 
 
 def test_first_agent_two_ranks_unseeded_across_the_pretraining_boundary(tmp_path):

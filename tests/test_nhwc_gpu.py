@@ -128,7 +128,8 @@ def test_nhwc_rejects_unsupported_channel_counts():
     assert nat.lib().mgvae_conv2d_nhwc_fwd(ctypes.byref(d), vp(t), vp(t), None, vp(t), None, stream()) == -1
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 48, 30), (2, 128, 24, 15), (2, 256, 12, 8), (3, 512, 6, 4), (2, 1024, 3, 2), (2, 64, 192, 30)])
+@pytest.mark.parametrize("shape", [(3, 64, 48, 30), (2, 128, 24, 15), (2, 256, 12, 8), (3, 512, 6, 4), (2, 1024, 3, 2), (2, 64, 192, 30), (3, 32, 48, 30),
+                                   (2, 32, 192, 30)])
 @pytest.mark.parametrize("mode,act", [(1, 1), (2, 1), (1, 2), (0, 0)])
 def test_norm_cbam_channels_last(shape, mode, act):
     """InstanceNorm -> CBAM -> (+residual) -> activation on channels-last tensors (u never materialised, channel
@@ -858,7 +859,7 @@ def test_nhwc_bf16_conv_three_products(g):
     check("nhwc bf16 dw %s" % (g,), dw, 1.0 + wr.grad)
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 48, 30), (2, 256, 12, 8), (2, 1024, 3, 2)])
+@pytest.mark.parametrize("shape", [(3, 64, 48, 30), (2, 256, 12, 8), (2, 1024, 3, 2), (3, 32, 48, 30)])
 @pytest.mark.parametrize("mode,act", [(1, 1), (2, 1)])
 def test_norm_cbam_channels_last_bf16_storage(shape, mode, act):
     """the fused InstanceNorm / CBAM op with bf16 STORAGE of the big tensors (statistics, gates, arithmetic fp32): against the
@@ -898,3 +899,82 @@ def test_norm_cbam_channels_last_bf16_storage(shape, mode, act):
         check(tag + " dres", rd.grad.float(), rr.grad, 4e-3)
     for k in sd:
         check(tag + " d" + k, ps[k].grad, sdr[k].grad, 1e-2)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(3, 96, 60, (4, 1), (2, 1), (1, 0)), (3, 96, 60, (1, 4), (1, 2), (0, 1)), (2, 384, 60, (4, 1), (2, 1), (1, 0)),
+                                  (5, 17, 9, (1, 4), (1, 2), (0, 1))])
+def test_one_channel_conv_writes_channels_last(geom, storage):
+    """the encoder stems' first conv (graph/encodingBlock.py:11-14,42-45: one input channel -> 32, LeakyReLU) written
+    channels-last by csrc/thin_nhwc.hip: forward against torch fp64; the weight gradient with the activation gradient applied
+    inside the kernel (mask) and with an already-masked gradient (the deferred form the stems use); accumulation into dw"""
+    from hipops import _native as nat
+    from hipops import functional as HF
+    L = nat.lib()
+    N, H, W, k, s, p = geom
+    torch.manual_seed(3)
+    x = torch.randn(N, 1, H, W)
+    w = torch.randn(32, 1, *k) * 0.5
+    dy = torch.randn(N, 32, (H + 2 * p[0] - k[0]) // s[0] + 1, (W + 2 * p[1] - k[1]) // s[1] + 1)
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    yr = F.leaky_relu(F.conv2d(xr, wr, None, s, p), 0.01)
+    yr.backward(dy.double())
+    dt = torch.bfloat16 if storage == "bf16" else torch.float32
+    tol = 8e-3 if storage == "bf16" else 2e-5
+    wd = torch.nn.Parameter(w.to(dev))
+    y = HF.conv2d_c1_cl(x.to(dev), wd, s, p, HF.ACT_LEAKY, 0.01, dtype=dt)
+    assert y.dtype == dt and HF.cl_pitch(y) == 32
+    check("conv_c1 %s %s fwd" % (geom, storage), y.float(), yr.detach(), tol)
+    # (a) the kernel applies LeakyReLU'(y) itself; in bf16 storage dy is rounded once more
+    y.backward(cl(dy).to(dt))
+    check("conv_c1 %s %s dw (mask in the kernel)" % (geom, storage), wd.grad, wr.grad, tol)
+    # (b) deferred: the consumer has applied the mask; a second backward ACCUMULATES
+    OH, OW = dy.shape[2:]
+    d = nat.ConvDesc(N, 1, H, W, 32, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], 1, 0, 32, 0, HF.ACT_LEAKY, 0.01)
+    g = cl(dy * torch.where(yr.detach() > 0, 1.0, 0.01).float()).to(dt)
+    dw = wd.grad.clone()
+    assert L.mgvae_conv2d_c1_nhwc_bwd_weight(ctypes.byref(d), vp(x.to(dev).contiguous()), vp(g), None, vp(dw), 1 if storage == "bf16" else 0, stream()) == 0
+    check("conv_c1 %s %s dw (deferred, accumulated)" % (geom, storage), dw, 2 * wr.grad, tol)
+    # refusals: more than one input channel, too many taps, a sigmoid
+    bad = nat.ConvDesc(N, 2, H, W, 32, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], 2, 0, 32, 0, 0, 0.0)
+    assert L.mgvae_conv2d_c1_nhwc_fwd(ctypes.byref(bad), vp(g), vp(dw), vp(g), 0, stream()) == -1
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 96, 60), (2, 32, 17, 9), (2, 128, 6, 5)])
+def test_conv_to_one_channel_reads_channels_last(shape, storage):
+    """the decoder's fit2 + Sigmoid (graph/decoder.py:186,217) on the channels-last map: forward, dx, dw against torch fp64 on
+    the same (rounded) input values; a frozen weight still gives dx"""
+    from hipops import functional as HF
+    N, C, H, W = shape
+    torch.manual_seed(4)
+    dt = torch.bfloat16 if storage == "bf16" else torch.float32
+    x = (torch.randn(shape) * 0.7).to(dt).float()
+    w = torch.randn(1, C, 1, 1) * 0.3
+    dy = torch.randn(N, 1, H, W)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = torch.sigmoid(F.conv2d(xr, wr))
+    yr.backward(dy.double())
+    xd = cl(x).to(dt).requires_grad_(True)
+    wd = torch.nn.Parameter(w.to(dev))
+    y = HF.conv2d_to1_cl(xd, wd, HF.ACT_SIGMOID)
+    assert tuple(y.shape) == (N, 1, H, W) and y.dtype == torch.float32 and y.is_contiguous()
+    check("conv_to1 %s %s fwd" % (shape, storage), y, yr.detach(), 2e-5)
+    y.backward(dy.to(dev))
+    check("conv_to1 %s %s dx" % (shape, storage), xd.grad.float(), xr.grad, 8e-3 if storage == "bf16" else 2e-5)
+    check("conv_to1 %s %s dw" % (shape, storage), wd.grad, wr.grad, 2e-5)
+    wd2 = torch.nn.Parameter(w.to(dev), requires_grad=False)
+    xd2 = cl(x).to(dt).requires_grad_(True)
+    HF.conv2d_to1_cl(xd2, wd2, HF.ACT_SIGMOID).backward(dy.to(dev))
+    assert torch.equal(xd2.grad, xd.grad) and wd2.grad is None
+
+
+def test_storage_cast_round_trip():
+    from hipops import functional as HF
+    x = cl(torch.randn(3, 64, 12, 10)).requires_grad_(True)
+    y = HF.cast_cl(x, torch.bfloat16)
+    assert y.dtype == torch.bfloat16 and HF.cl_pitch(y) == 64 and torch.equal(y, x.detach().bfloat16())
+    g = cl(torch.randn(3, 64, 12, 10)).bfloat16()
+    y.backward(g)
+    assert x.grad.dtype == torch.float32 and torch.equal(x.grad, g.float())
+    assert HF.cast_cl(x, torch.float32) is x
