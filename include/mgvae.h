@@ -248,6 +248,11 @@ int mgvae_norm_cbam_nhwc_bwd(const void* x, const float* gamma, const float* bet
                              void* dres, float* dgamma, float* dbeta, float* dw1, float* dw2, float* dwsp,
                              float* scratch, int N, int C, int H, int W, int y_ctot, int y_coff, int mode, int act,
                              float slope, int storage, void* stream);
+/* the CBAM gate MLP's weight gradients alone: after mgvae_norm_cbam_nhwc_bwd was called with dw1 = dw2 = NULL, from the
+ * same `save` / `scratch` buffers, on any stream ordered after that call (the launch chains put it on the weight-gradient
+ * stream: only the optimizer waits for it)                                                                             */
+int mgvae_norm_cbam_nhwc_bwd_mlp_wgrad(const float* save, const float* scratch, float* dw1, float* dw2, int N, int C, int H,
+                                       int W, void* stream);
 /* InstanceNorm2d (+ReLU / LeakyReLU) alone on channels-last tensors (graph/decoder.py:81-83,124-126); `stats`:
  * mgvae_instance_norm_nhwc_stats_floats() floats (6 N C kept for backward + the chunked statistics pass's partials), `scratch`: 2 N C floats; and the bias gradient of a transposed conv (sum over pixel rows).   */
 size_t mgvae_instance_norm_nhwc_stats_floats(int N, int C, int H, int W);   /* floats of the `stats` workspace below */

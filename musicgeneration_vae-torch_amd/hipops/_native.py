@@ -84,6 +84,7 @@ SIGNATURES = {
     "mgvae_norm_cbam_nhwc_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_norm_cbam_nhwc_fwd": (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_int, c_float, c_int, P]),
     "mgvae_norm_cbam_nhwc_bwd": (c_int, [P] * 17 + [c_int] * 8 + [c_float, c_int, P]),
+    "mgvae_norm_cbam_nhwc_bwd_mlp_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "mgvae_instance_norm_nhwc_stats_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mgvae_instance_norm_nhwc_fwd": (c_int, [P, P, P, P, P] + [c_int] * 6 + [c_float, c_int, c_float, c_int, P]),
     "mgvae_instance_norm_nhwc_bwd": (c_int, [P] * 9 + [c_int] * 7 + [c_float, c_int, P]),

@@ -138,6 +138,15 @@ def _side_for(n, trainable, need_dx, touched):
     return cur_raw, side.cuda_stream
 
 
+def _gate_wgrad(ch, f1, f2, s_save, s_scr, s_d1, s_d2, N, C, H, W, s_st, s_side):
+    """the CBAM gate MLP's weight gradients as a launch of their own on the weight-gradient stream: mgvae_norm_cbam_nhwc_bwd was
+    given NULL for them, so the data-gradient chain does not wait for a kernel only the optimizer needs (it was 0.25 ms per
+    step alone on the chip -- tools/trace_timeline.py)"""
+    if f1 or f2:
+        ch.call("mgvae_stream_fork", s_st, s_side)
+        ch.call("mgvae_norm_cbam_nhwc_bwd_mlp_wgrad", s_save, s_scr, s_d1 if f1 else None, s_d2 if f2 else None, N, C, H, W, s_side)
+
+
 def _dense_cl(dy, like, pitch):
     """the incoming gradient as a channels-last tensor of ``like``'s storage type whose pixel pitch is ``pitch``"""
     dy = HF._as_cl(dy, like)
@@ -200,7 +209,8 @@ class _ResidualFn(torch.autograd.Function):
             em = _Emit(ch, eng, s_ws, s_st)
             k, o, p = (3, 3), (1, 1), (1, 1)
             ch.call("mgvae_norm_cbam_nhwc_bwd", s_t2, s_g, s_b, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt2, s_dres, s_dg, s_db,
-                    s_dc1, s_dc2, s_dsa, s_scr, N, C, H, W, C, 0, 2, HF.ACT_RELU, 0.01, st, s_st)
+                    None, None, s_dsa, s_scr, N, C, H, W, C, 0, 2, HF.ACT_RELU, 0.01, st, s_st)
+            _gate_wgrad(ch, flags[4], flags[5], s_save, s_scr, s_dc1, s_dc2, N, C, H, W, s_st, s_side)
             if flags[1]:
                 ch.call("mgvae_stream_fork", s_st, s_side)
                 em.bwd_weight(_desc(N, C, H, W, C, H, W, k, o, p, C, C), s_t1, s_dt2, s_dw2, s_side)
@@ -221,7 +231,7 @@ class _ResidualFn(torch.autograd.Function):
         dx = _new(N, C, H, W, x) if need_dx else None
         scr = _f32(nscr, x.device)
         ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
-        main, side = _side_for(N, flags[0] or flags[1], need_dx, (x, t1, dt2, dt1))
+        main, side = _side_for(N, flags[0] or flags[1] or flags[4] or flags[5], need_dx, (x, t1, dt2, dt1, save, scr))
         ch.run([x.data_ptr(), t1.data_ptr(), t2.data_ptr(), y.data_ptr(), dy.data_ptr(), wt1.data_ptr(), wt2.data_ptr(),
                 gamma.data_ptr(), beta.data_ptr(), ca1.data_ptr(), ca2.data_ptr(), sa.data_ptr(), save.data_ptr(), dt2.data_ptr(),
                 dres.data_ptr(), dt1.data_ptr(), _ptr(dx), _ptr(_grad(gamma)), _ptr(_grad(beta)), _ptr(_grad(ca1)), _ptr(_grad(ca2)),
@@ -290,8 +300,9 @@ class _ConvNormCbamFn(torch.autograd.Function):
             (s_x, s_t, s_y, s_dy, s_wt, s_g, s_b, s_c1, s_c2, s_sa, s_save, s_dt, s_dx, s_dg, s_db, s_dc1, s_dc2, s_dsa, s_dw,
              s_scr, s_ws, s_st, s_side) = ch.slots(23)
             em = _Emit(ch, eng, s_ws, s_st)
-            ch.call("mgvae_norm_cbam_nhwc_bwd", s_t, s_g, s_b, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt, None, s_dg, s_db, s_dc1,
-                    s_dc2, s_dsa, s_scr, N, Cy, OH, OW, Cy, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+            ch.call("mgvae_norm_cbam_nhwc_bwd", s_t, s_g, s_b, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt, None, s_dg, s_db, None,
+                    None, s_dsa, s_scr, N, Cy, OH, OW, Cy, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+            _gate_wgrad(ch, flags[3], flags[4], s_save, s_scr, s_dc1, s_dc2, N, Cy, OH, OW, s_st, s_side)
             if flags[0]:
                 ch.call("mgvae_stream_fork", s_st, s_side)
                 em.bwd_weight(_desc(N, Cx, H, W, Cy, OH, OW, (KH, KW), stride, pad, xct, Cy), s_x, s_dt, s_dw, s_side)
@@ -305,7 +316,7 @@ class _ConvNormCbamFn(torch.autograd.Function):
         dx = _new(N, Cx, H, W, x) if need_dx else None
         scr = _f32(nscr, x.device)
         ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
-        main, side = _side_for(N, flags[0], need_dx, (x, dt))
+        main, side = _side_for(N, flags[0] or flags[3] or flags[4], need_dx, (x, dt, save, scr))
         ch.run([x.data_ptr(), t.data_ptr(), y.data_ptr(), dy.data_ptr(), wt.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                 ca1.data_ptr(), ca2.data_ptr(), sa.data_ptr(), save.data_ptr(), dt.data_ptr(), _ptr(dx), _ptr(_grad(gamma)),
                 _ptr(_grad(beta)), _ptr(_grad(ca1)), _ptr(_grad(ca2)), _ptr(_grad(sa)), _ptr(_grad(w)), scr.data_ptr(), _ptr(ws),
@@ -411,7 +422,8 @@ class _DeConvFn(torch.autograd.Function):
              s_side) = ch.slots(53)
             em = _Emit(ch, eng, s_ws, s_st)
             ch.call("mgvae_norm_cbam_nhwc_bwd", s_t3, s_g3, s_b3, s_y, s_dy, s_c1, s_c2, s_sa, s_save, s_dt3, None, s_dg3, s_db3,
-                    s_dc1, s_dc2, s_dsa, s_scr3, N, Co, OH, OW, Co, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+                    None, None, s_dsa, s_scr3, N, Co, OH, OW, Co, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+            _gate_wgrad(ch, flags[14], flags[15], s_save, s_scr3, s_dc1, s_dc2, N, Co, OH, OW, s_st, s_side)
             d3 = lambda xc: _desc(N, 2 * Co, OH, OW, Co, OH, OW, (1, 1), (1, 1), (0, 0), xc, Co)
             if flags[11]:
                 ch.call("mgvae_stream_fork", s_st, s_side)
@@ -421,7 +433,8 @@ class _DeConvFn(torch.autograd.Function):
                     s_scrb, N, Co, OH, OW, 2 * Co, 0, HF.ACT_RELU, 0.01, st, s_st)
             if pp:
                 ch.call("mgvae_norm_cbam_nhwc_bwd", s_ta, s_ga, s_bta, s_cat, s_dcat, s_ac1, s_ac2, s_asa, s_sta, s_dta, None, s_dga,
-                        s_dbta, s_dac1, s_dac2, s_dasa, s_scra, N, Co, OH, OW, 2 * Co, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+                        s_dbta, None, None, s_dasa, s_scra, N, Co, OH, OW, 2 * Co, 0, 1, HF.ACT_RELU, 0.01, st, s_st)
+                _gate_wgrad(ch, flags[8], flags[9], s_sta, s_scra, s_dac1, s_dac2, N, Co, OH, OW, s_st, s_side)
             else:
                 ch.call("mgvae_instance_norm_nhwc_bwd", s_ta, s_ga, s_sta, s_cat, s_dcat, s_dta, s_dga, s_dbta, s_scra, N, Co, OH, OW,
                         2 * Co, 0, HF.ACT_RELU, 0.01, st, s_st)
@@ -457,7 +470,8 @@ class _DeConvFn(torch.autograd.Function):
         scra = _f32(n3 if pp else 2 * N * Co, x.device)
         scrb = _f32(2 * N * Co, x.device)
         ws = torch.empty(wsn, device=x.device, dtype=torch.uint8) if wsn else None
-        main, side = _side_for(N, any(flags[:4]) or flags[11], need_dx, (x, cat, dt3, dta, dtb))
+        main, side = _side_for(N, any(flags[:4]) or flags[11] or flags[8] or flags[9] or flags[14] or flags[15], need_dx,
+                               (x, cat, dt3, dta, dtb, save, scr3, sta, scra))
         g = _grad
         ch.run([x.data_ptr(), ta.data_ptr(), tb.data_ptr(), cat.data_ptr(), sta.data_ptr(), stb.data_ptr(), t3.data_ptr(), y.data_ptr(),
                 save.data_ptr(), dy.data_ptr(), wka.data_ptr(), wkb.data_ptr(), wt3.data_ptr(), ga.data_ptr(), bta.data_ptr(),
@@ -668,8 +682,9 @@ class _TrunkEntryFn(torch.autograd.Function):
                 fl = flags[7 * si:7 * si + 7]
                 (s_wt2, s_g, s_b, s_c1, s_c2, s_sa, s_t1, s_t2, s_save, s_dt2, s_dt1, s_scr, s_dw1, s_dw2, s_dg, s_db, s_dc1, s_dc2,
                  s_dsa) = ch.slots(19)
-                ch.call("mgvae_norm_cbam_nhwc_bwd", s_t2, s_g, s_b, s_cat, s_dcat, s_c1, s_c2, s_sa, s_save, s_dt2, None, s_dg, s_db, s_dc1,
-                        s_dc2, s_dsa, s_scr, N, 32, OH, OW, 64, 32 * si, 1, HF.ACT_LEAKY, 0.01, HF.STORE_F32, s_st)
+                ch.call("mgvae_norm_cbam_nhwc_bwd", s_t2, s_g, s_b, s_cat, s_dcat, s_c1, s_c2, s_sa, s_save, s_dt2, None, s_dg, s_db, None,
+                        None, s_dsa, s_scr, N, 32, OH, OW, 64, 32 * si, 1, HF.ACT_LEAKY, 0.01, HF.STORE_F32, s_st)
+                _gate_wgrad(ch, fl[4], fl[5], s_save, s_scr, s_dc1, s_dc2, N, 32, OH, OW, s_st, s_side)
                 d2 = _desc(N, 32, H1, W1, 32, OH, OW, k2, s2, p2, 32, 32)
                 if fl[1]:
                     ch.call("mgvae_stream_fork", s_st, s_side)
@@ -698,7 +713,7 @@ class _TrunkEntryFn(torch.autograd.Function):
             _, wt2 = _weights(eng, w2)
             dt2, dt1, scr = HF.new_channels_last(N, 32, OH, OW, dev, torch.float32), HF.new_channels_last(N, 32, H1, W1, dev, torch.float32), _f32(nscr, dev)
             tmp += [dt2, dt1, scr]
-            touched += [t1, dt2, dt1]
+            touched += [t1, dt2, dt1, save, scr]
             addr_stems += [wt2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(), t2.data_ptr(),
                            save.data_ptr(), dt2.data_ptr(), dt1.data_ptr(), scr.data_ptr(), _ptr(_grad(w1)), _ptr(_grad(w2)), _ptr(_grad(g)),
                            _ptr(_grad(b)), _ptr(_grad(c1)), _ptr(_grad(c2)), _ptr(_grad(sa))]
@@ -904,7 +919,7 @@ class _DecoderFrontFn(torch.autograd.Function):
             co1, h1, w1_ = shapes[si]
             du, dt2, dt1, scr = f(B, 1024, 6, 3), f(B, 1024, 6, 3), f(B, co1), f(nscr)
             tmp += [du, dt2, dt1, scr]
-            touched += [t1, dt2, dt1]
+            touched += [t1, dt2, dt1, save, scr]
             addr_st += [w1.data_ptr(), w2.data_ptr(), g.data_ptr(), b.data_ptr(), c1.data_ptr(), c2.data_ptr(), sa.data_ptr(), t1.data_ptr(),
                         t2.data_ptr(), u.data_ptr(), stats.data_ptr(), save.data_ptr(), du.data_ptr(), dt2.data_ptr(), dt1.data_ptr(), scr.data_ptr(),
                         _ptr(_grad(w1)), _ptr(_grad(w2)), _ptr(_grad(g)), _ptr(_grad(b)), _ptr(_grad(c1)), _ptr(_grad(c2)), _ptr(_grad(sa))]

@@ -1,0 +1,18 @@
+#!/bin/bash
+# same-box A/B: the tree of the previous commit (_ab/old) against the working tree, interleaved
+set -u
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3ab2; mkdir -p $O
+for r in 1 2; do
+  for n in old new; do
+    if [ $n = old ]; then D=$R/_ab/old; else D=$R; fi
+    cd $D
+    for cfg in "f32 64" "bf16 32"; do
+      set -- $cfg
+      MGVAE_AUTOTUNE_FILE=$O/tune_$n.txt timeout -k 10 250 python3 bench.py --no-cpu-baseline --no-roofline --dtype $1 --batch $2 --steps 30 --warmup 5 2> $O/err_$n.txt | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$n round $r $1 b$2: %.3f ms/step (median %.3f)' % (d['ms_per_step'], d['ms_per_step_median']))" || tail -3 $O/err_$n.txt
+    done
+  done
+done
+cd $R && timeout -k 10 200 python3 tools/bench_gan.py 16 bf16 20 2>/dev/null | grep "^{" | cut -c1-200
+cd $R/_ab/old && timeout -k 10 200 python3 tools/bench_gan.py 16 bf16 20 2>/dev/null | grep "^{" | cut -c1-200

@@ -36,3 +36,22 @@ for name, N, Cx, H, W, Cy, k, st, p in CASES:
     mb = (x.numel() + y.numel()) * 4 / 1e6
     print("%-18s | x3 fwd/dgrad/wgrad %4.0f %4.0f %4.0f us (%3.0f %3.0f %3.0f TF) | tensors %.0f MB fp32" % (
         (name,) + tuple(b) + tuple(flops/u/1e6 for u in b) + (mb,)), flush=True)
+# the one-channel ends (csrc/thin_nhwc.hip): HBM-bound passes over the 32- / 64-channel map
+for name, N, H, W, k, st, p in (("c1 time N64", 64, 384, 60, (4, 1), (2, 1), (1, 0)), ("c1 pitch N64", 64, 384, 60, (1, 4), (1, 2), (0, 1)),
+                                ("c1 time N128", 128, 96, 60, (4, 1), (2, 1), (1, 0)), ("c1 time N32", 32, 384, 60, (4, 1), (2, 1), (1, 0))):
+    OH = (H + 2*p[0] - k[0])//st[0] + 1; OW = (W + 2*p[1] - k[1])//st[1] + 1
+    x = torch.randn(N, 1, H, W, device=dev); w = torch.randn(32, 1, *k, device=dev); y = torch.empty(N, OH, OW, 32, device=dev)
+    dw = torch.zeros(32, k[0] * k[1], device=dev)
+    d = nat.ConvDesc(N, 1, H, W, 32, OH, OW, k[0], k[1], st[0], st[1], p[0], p[1], 1, 0, 32, 0, 2, 0.01)
+    f = timeit(lambda: L.mgvae_conv2d_c1_nhwc_fwd(ctypes.byref(d), vp(x), vp(w), vp(y), 0, s))
+    b = timeit(lambda: L.mgvae_conv2d_c1_nhwc_bwd_weight(ctypes.byref(d), vp(x), vp(y), None, vp(dw), 0, s))
+    mb = y.numel() * 4 / 1e6
+    print("%-14s | fwd %5.1f us (%.2f TB/s)  wgrad %5.1f us (%.2f TB/s) | map %.0f MB" % (name, f, mb / f, b, mb / b, mb), flush=True)
+for name, N in (("to1 N64", 64), ("to1 N32", 32), ("to1 N16", 16)):
+    rows = N * 96 * 60
+    x = torch.randn(rows, 64, device=dev); w = torch.randn(64, device=dev); y = torch.empty(rows, device=dev); dy = torch.randn(rows, device=dev)
+    dx = torch.empty_like(x); dw = torch.zeros(64, device=dev)
+    f = timeit(lambda: L.mgvae_conv2d_to1_nhwc_fwd(vp(x), vp(w), vp(y), rows, 64, 64, 0, 3, 0.0, 0, s))
+    b = timeit(lambda: L.mgvae_conv2d_to1_nhwc_bwd(vp(x), vp(w), vp(y), vp(dy), vp(dx), vp(dw), rows, 64, 64, 0, 3, 0.0, 0, s))
+    mb = x.numel() * 4 / 1e6
+    print("%-14s | fwd %5.1f us (%.2f TB/s)  bwd %5.1f us (%.2f TB/s, read + write) | map %.0f MB" % (name, f, mb / f, b, 2 * mb / b, mb), flush=True)
