@@ -141,7 +141,10 @@ int mgvae_conv2d_nhwc_bf16_bwd_weight(const MgvaeConvDesc* d, const void* x, con
  * points above (x / y / dw fp32, fp32 accumulation), but every fp32 operand value enters the matrix pipe as the exact sum
  * of three bf16 values and each product as six bf16 MFMAs (relative error < 2^-22 per product: fp32 grade) -- 16 / 6 of
  * the fp32 MFMA rate.  Activations are split while staged; weights once per optimizer step by mgvae_pack_conv_weights_x3
- * into wk3 [3, Cy, KH*KW, Cx] (forward) and wt3 [3, Cx, KH*KW, Cy] (data gradient / transposed-conv forward), bf16.
+ * into wk3 (forward; rows = Cy, k = Cx) and wt3 (data gradient / transposed-conv forward; rows = Cx, k = Cy), bf16, 3 * Cy *
+ * KH*KW * Cx elements each.  The buffers are OPAQUE to the caller (only these kernels read them); their layout is
+ * [plane][row][tap][k], or -- when both channel counts are multiples of 32 -- block-major [tap][k / 32][row][plane][32], where
+ * the 24 KB a 128-row K tile of 32 needs are one contiguous run of whole cache lines (csrc/conv_nhwc_x3.inc::x3w_blocked).
  * Channel counts multiples of 16, slice offsets multiples of 4.                                                         */
 int mgvae_pack_conv_weights_x3(const float* w, void* wk3, void* wt3, int Cy, int T, int Cx, void* stream);
 /* every conv weight of a network in one launch per optimizer step: `items` is a DEVICE array of n records

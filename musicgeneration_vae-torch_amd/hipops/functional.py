@@ -1170,7 +1170,7 @@ def _cl_mask(t, act, slope):
 
 class _WeightCopies:
     """the matrix-pipe copies of a network's conv weights -- planes = 1: bf16 (wk [Cy, T, Cx], wt [Cx, T, Cy]) for the
-    bf16-storage island; planes = 3: the three-way split (wk3 [3, Cy, T, Cx], wt3 [3, Cx, T, Cy]) of the fp32 island
+    bf16-storage island; planes = 3: the three-way split (wk3: rows Cy, wt3: rows Cx; 3 * numel elements each, layout owned by the library -- include/mgvae.h) of the fp32 island
     (csrc/conv_nhwc_x3.inc) -- refreshed ONCE per optimizer step.  A weight inside a FlatParams buffer registers here the
     first time a conv uses it (and is packed alone that once); from the next step on all registered weights are repacked
     by one grouped launch when the first of them is asked for, and every other stream that asks waits for that launch's
@@ -1285,7 +1285,7 @@ def _x3_ok(cx, cy):
 
 
 def _x3_weights(w):
-    """(wk3, wt3): the fp32 channels-last master weight as three bf16 planes each way -- wk3 [3, Cy, T, Cx] for the forward
+    """(wk3, wt3): the fp32 channels-last master weight as three bf16 planes each way -- wk3 (rows Cy, k Cx) for the forward
     product, wt3 [3, Cx, T, Cy] for the data gradient (see _WeightCopies)."""
     return _weight_copies(w, 3, "_mg_x3")
 

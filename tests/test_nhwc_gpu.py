@@ -783,9 +783,15 @@ def test_nhwc_x3_conv_three_products_are_fp32_grade(g):
     nw = Cy * k * k * Cx
     wk3 = torch.empty(3 * nw, device=dev, dtype=torch.bfloat16); wt3 = torch.empty(3 * nw, device=dev, dtype=torch.bfloat16)
     assert L.mgvae_pack_conv_weights_x3(vp(wd), vp(wk3), vp(wt3), Cy, k * k, Cx, stream()) == 0
-    planes = wk3.view(3, Cy, k, k, Cx).float()
+    def planes_of(buf, rows, K):
+        """the three planes as [3, rows, k, k, K]: classic [plane][row][tap][k], or -- both channel counts multiples of 32 -- the
+        block-major [tap][k / 32][row][plane][32] of csrc/conv_nhwc_x3.inc::x3w_blocked"""
+        if Cy % 32 == 0 and Cx % 32 == 0:
+            return buf.view(k * k, K // 32, rows, 3, 32).permute(3, 2, 0, 1, 4).reshape(3, rows, k, k, K).float()
+        return buf.view(3, rows, k, k, K).float()
+    planes = planes_of(wk3, Cy, Cx)
     assert torch.equal((planes[0] + planes[1] + planes[2]).permute(0, 3, 1, 2).cpu(), w), "h + m + l must be the fp32 weight, exactly"
-    planes = wt3.view(3, Cx, k, k, Cy).float()
+    planes = planes_of(wt3, Cx, Cy)
     assert torch.equal((planes[0] + planes[1] + planes[2]).permute(3, 0, 1, 2).cpu(), w)
     d = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, s, s, p, p, Cx, 0, Cy, 0, 0, 0.0)
     got, ref = {}, {}
@@ -978,3 +984,33 @@ def test_storage_cast_round_trip():
     y.backward(g)
     assert x.grad.dtype == torch.float32 and torch.equal(x.grad, g.float())
     assert HF.cast_cl(x, torch.float32) is x
+
+
+@pytest.mark.parametrize("g", [(3, 48, 12, 10, 80, 3, 1, 1), (2, 16, 9, 7, 48, 3, 2, 1), (2, 80, 6, 5, 16, 1, 1, 0), (130, 48, 4, 4, 144, 3, 1, 1),
+                               (2, 64, 12, 10, 160, 3, 1, 1), (3, 128, 9, 7, 64, 4, 2, 1)])
+def test_nhwc_x3_ring_form(g):
+    """the LDS-DMA ring form of the x3 forward product (csrc/conv_nhwc_x3_ring.inc, an experiment switched on by MGVAE_X3_RING;
+    DESIGN.md section 3.12): against torch fp64 at the family's tolerance, with bias and ReLU, ragged tiles in both directions,
+    padding taps (zero fill of out-of-range lanes), 2 / 3 / 6 stages; both weight-plane layouts (classic: a channel count that
+    is not a multiple of 32; block-major otherwise)."""
+    import os
+    from hipops import _native as nat
+    L = nat.lib()
+    N, Cx, H, W_, Cy, k, s, p = g
+    OH, OW = (H + 2 * p - k) // s + 1, (W_ + 2 * p - k) // s + 1
+    torch.manual_seed(11)
+    x = torch.randn(N, Cx, H, W_); w = torch.randn(Cy, Cx, k, k) * 0.2; b = torch.randn(Cy)
+    yr = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p))
+    xd, wd = cl(x), cl(w)
+    nw = Cy * k * k * Cx
+    wk3 = torch.empty(3 * nw, device=dev, dtype=torch.bfloat16); wt3 = torch.empty(3 * nw, device=dev, dtype=torch.bfloat16)
+    assert L.mgvae_pack_conv_weights_x3(vp(wd), vp(wk3), vp(wt3), Cy, k * k, Cx, stream()) == 0
+    d = nat.ConvDesc(N, Cx, H, W_, Cy, OH, OW, k, k, s, s, p, p, Cx, 0, Cy, 0, 1, 0.0)
+    try:
+        for stages in (2, 3, 6):
+            os.environ["MGVAE_X3_RING"] = str(stages)
+            y = cl(torch.full((N, Cy, OH, OW), 7.0))
+            assert L.mgvae_conv2d_nhwc_x3_fwd(ctypes.byref(d), vp(xd), vp(wk3), vp(b.to(dev)), vp(y), None, None, 0, stream()) == 0
+            check("x3 ring form %s, %d stages" % (g, stages), y, yr, 2e-5)
+    finally:
+        os.environ.pop("MGVAE_X3_RING", None)
