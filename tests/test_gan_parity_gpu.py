@@ -711,9 +711,10 @@ def test_train_gan_iteration_bf16_storage(tmp_path, monkeypatch):
         got, want, exact = float(meters[meter].val), float(o_r[key]), float(o_x[key])
         REPORT.append("bf16 train_gan %-16s hip %.6f  rounding oracle %.6f  exact %.6f" % (key, got, want, exact))
         # the feature discriminator reads the BINARISED fake pair: one bf16 rounding that falls the other way flips notes, and the
-        # same build on the same box gives 1.382 - 1.405 from run to run (tools/r3_run25.sh, five runs; oracle 1.4048); the two other
-        # losses sit within 1e-3 of the oracle in every run
-        rel = 2.5e-2 if key == "feature_loss" else 1e-2
+        # same build on the same box gives 1.378 - 1.405 from run to run (tools/r3_run25.sh and the full-suite runs: -1.9 %, -1.6 %,
+        # -0.4 %, -0.2 %, 0.0 % of the oracle's 1.4048); the bound is twice the worst of those.  The two other losses sit within
+        # 1e-3 of the oracle in every run
+        rel = 4e-2 if key == "feature_loss" else 1e-2
         assert abs(got - want) <= max(2 * abs(want - exact), rel * abs(exact)), (key, got, want, exact)
 
     def flat(d, names):
