@@ -1,36 +1,44 @@
-"""host-side view of one training step: which aten ops (copies, fills, adds ...) the autograd tape and the host layer
-issue besides the library's own launches (torch.profiler, CPU activity only)"""
-import os, sys, collections
+"""cProfile of the host side of the pre-training step at a small batch (where the host bounds the step): top functions by
+cumulative and by own time.  usage: python tools/host_profile.py [batch] [dtype]"""
+import sys, os, cProfile, pstats, io
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "musicgeneration_vae-torch_amd"))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'musicgeneration_vae-torch_amd'))
 import torch
-import __graft_entry__ as ge; ge.build()
+import bench
+import __graft_entry__ as ge
+ge.build()
 from hipops import functional as HF
 from hipops.train import PretrainStep
 from graph.model import Model
 from graph.z_discriminator import BarZDiscriminator, PhraseZDiscriminator
 from graph.loss.bar_loss import Loss, DLoss
-dev = "cuda"
-HF.set_compute_dtype(sys.argv[1] if len(sys.argv) > 1 else "f32")
-B = 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+HF.set_compute_dtype(sys.argv[2] if len(sys.argv) > 2 else "bf16")
+dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-gen, zb, zp = Model().to(dev), BarZDiscriminator().to(dev), PhraseZDiscriminator().to(dev)
-step = PretrainStep(gen, zb, zp, Loss().to(dev), DLoss().to(dev), lr=0.002)
-g = torch.Generator().manual_seed(1)
-batch = [(torch.rand(B, 1, 96, 60, generator=g) < 0.05).float().to(dev), (torch.rand(B, 1, 96, 60, generator=g) < 0.05).float().to(dev),
-         (torch.rand(B, 1, 384, 60, generator=g) < 0.05).float().to(dev), torch.randint(0, 332, (B,), generator=g).to(dev)]
-for _ in range(3):
-    step(*batch)
+gen, zb, zp = Model().to(dev).train(), BarZDiscriminator().to(dev), PhraseZDiscriminator().to(dev)
+for d in (zb, zp):
+    for p in d.parameters():
+        p.requires_grad = False
+HF.manual_seed(1234, 0)
+step = PretrainStep(gen, zb, zp, Loss().to(dev), DLoss(), lr=0.002)
+batch = bench.synth_batch(B, 1234, dev)
+for _ in range(5): step(*batch)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+import time
+t0 = time.perf_counter()
+for _ in range(20):
     step(*batch)
-    torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25))
-cnt = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::clone", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::contiguous", "aten::empty_like", "aten::zeros"):
-        st = [f for f in (ev.stack or []) if "musicgeneration" in f or "hipops" in f or "graph/" in f]
-        cnt[(ev.name, st[0] if st else "(autograd / no python frame)")] += 1
-for (name, where), n in cnt.most_common(40):
-    print("%4d  %-18s %s" % (n, name, where))
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("20 steps: host %.2f ms/step, wall %.2f ms/step" % ((t1 - t0) * 50, (t2 - t0) * 50))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(10): step(*batch)
+pr.disable()
+torch.cuda.synchronize()
+for key in ("cumulative", "tottime"):
+    sio = io.StringIO()
+    pstats.Stats(pr, stream=sio).sort_stats(key).print_stats(28)
+    print("\n".join(l[:150] for l in sio.getvalue().splitlines()[4:44]))
