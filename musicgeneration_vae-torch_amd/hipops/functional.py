@@ -84,6 +84,14 @@ def _desc(N, Cx, H, W, Cy, OH, OW, k, s, p, x_ctot, y_ctot, act, slope):
     return nat.ConvDesc(N, Cx, H, W, Cy, OH, OW, k[0], k[1], s[0], s[1], p[0], p[1], x_ctot, 0, y_ctot, 0, act, slope)
 
 
+# One process drives one GPU: torch's autograd engine would still hand every backward node of a CUDA tensor to a worker thread
+# of its own, and that hand-over (a condition variable per node, the GIL passed back and forth between the caller and the
+# worker that runs our Python backward functions) is what made the small-batch steps bimodal -- 7.8 or 8.9-9.5 ms at 32 bars
+# bf16 from one run to the next, 15.5-16.0 against 15.1 ms for the GAN iteration at 16 bars (tools/r3_run28.sh).  Backward runs
+# on the calling thread instead (MGVAE_AUTOGRAD_THREAD=1 restores torch's default).
+if __import__("os").environ.get("MGVAE_AUTOGRAD_THREAD", "0") == "0":
+    torch.autograd.set_multithreading_enabled(False)
+
 USE_TRANSPOSED_W = __import__("os").environ.get("MGVAE_TW", "1") != "0"   # data-gradient / transposed-conv kernels read a [Cy][KK][Cx] copy of the weight
 import os as _os
 # direct (halo-tile, packed-weight, register-prefetched) conv kernels vs the implicit GEMM: MGVAE_DIRECT=0 (default)
