@@ -48,7 +48,8 @@ class Model(nn.Module):
         Call ``join_phrase`` before the result is consumed."""
         if not OVERLAP_TRUNKS or not phrase.is_cuda:
             return self.phrase_encoder(phrase)
-        cur = torch.cuda.current_stream()
+        from hipops import functional as _HF
+        cur = _HF.cur_stream()
         if getattr(self, "_side", None) is None:
             from hipops import functional as HF
             # the phrase trunk is the longer of the two concurrent chains (the critical path): high priority
@@ -89,7 +90,8 @@ class Model(nn.Module):
 
     def join_phrase(self):
         if OVERLAP_TRUNKS and getattr(self, "_side", None) is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            from hipops import functional as _HF
+            _HF.cur_stream().wait_stream(self._side)
 
     def forward(self, note, pre_note, phrase, position, is_train=True):
         phrase_feature = self.encode_phrase(phrase)

@@ -126,7 +126,7 @@ def _side_for(n, trainable, need_dx, touched):
         if HF._trunk_streams or HF._used_sides:
             HF._ensure_join_callback()
         return cur_raw, cur_raw
-    cur = torch.cuda.current_stream()
+    cur = HF.cur_stream()
     HF._wgrad_rr[0] += 1
     slot = 2 + HF._wgrad_rr[0] % HF.WGRAD_STREAMS
     side = HF.side_stream_of(cur, slot)

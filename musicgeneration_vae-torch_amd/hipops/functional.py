@@ -33,6 +33,24 @@ def _s():
     return _vp(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
+_stream_objs = {}
+
+
+def cur_stream():
+    """``torch.cuda.current_stream()`` without its ~9 us of Python device look-ups (123 calls and 1.1 ms per step at 32 bars,
+    tools/host_profile.py): the Stream object of the current raw stream, built once per (device, stream)."""
+    dev = torch._C._cuda_getDevice()
+    raw = torch._C._cuda_getCurrentRawStream(dev)
+    st = _stream_objs.get((dev, raw))
+    if st is None:
+        st = _stream_objs[(dev, raw)] = torch.cuda.current_stream()
+    return st
+
+
+def cur_raw_stream():
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _need_cuda(t, what):
     if not t.is_cuda:
         raise RuntimeError("%s: expected a ROCm device tensor; the MI355X hot path has no CPU fallback" % what)
@@ -284,7 +302,7 @@ def _join_sides(slot=None, parent=None):
     """make the caller's stream wait for every side stream used since the last join (end of a backward pass);
     ``slot``: only the side streams of that slot; ``parent``: only the side streams forked from that stream (and no
     trunk stream): what an early gradient bucket launched from the step's main stream has to wait for"""
-    cur = torch.cuda.current_stream()
+    cur = cur_stream()
     if slot is None and parent is None:
         for st in _trunk_streams:
             if st.device == cur.device and st.cuda_stream != cur.cuda_stream:
@@ -327,7 +345,7 @@ class _forked:
         self.tensors, self.slot = tensors, slot
 
     def __enter__(self):
-        cur = torch.cuda.current_stream()
+        cur = cur_stream()
         side = side_stream_of(cur, self.slot)
         side.wait_stream(cur)
         for t in self.tensors:
@@ -1234,8 +1252,8 @@ class _WeightCopies:
                       "pack_conv_weights_grouped")
             self.version = version
             self.event = torch.cuda.Event()
-            self.event.record(torch.cuda.current_stream())
-            self.waited = {torch.cuda.current_stream().cuda_stream}
+            self.event.record(cur_stream())
+            self.waited = {cur_raw_stream()}
             for ww, _, _ in self.copies.values():
                 ww._mg_copy_version = (version, ww._version)
         else:                                  # edited by a torch op inside the step: this one alone
@@ -1247,9 +1265,9 @@ class _WeightCopies:
     def _wait(self):
         if self.event is None:
             return
-        sid = torch.cuda.current_stream().cuda_stream
+        sid = cur_raw_stream()
         if sid not in self.waited:
-            torch.cuda.current_stream().wait_event(self.event)
+            cur_stream().wait_event(self.event)
             self.waited.add(sid)
 
 
